@@ -1,0 +1,97 @@
+"""Shared test plumbing: marker registration, import paths, oracle loaders.
+
+The oracle (oracle/) is test infrastructure: it is imported only from here, from
+__graft_entry__.smoke() and from bench.py's cpu_baseline leg — never by the product
+package (3d-point-clouds-autocomplete_amd/).
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG_DIR = os.path.join(ROOT, "3d-point-clouds-autocomplete_amd")
+for p in (ROOT, PKG_DIR):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+class OracleLib:
+    """ctypes view of oracle/libstructural_losses_ref.so (the C restatement)."""
+
+    def __init__(self):
+        so = os.path.join(ROOT, "oracle", "libstructural_losses_ref.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+        self.lib = ctypes.CDLL(so)
+
+    @staticmethod
+    def _p(a):
+        return a.ctypes.data_as(ctypes.c_void_p)
+
+    def nndistance(self, xyz1, xyz2):
+        xyz1, xyz2 = np.ascontiguousarray(xyz1, np.float32), np.ascontiguousarray(xyz2, np.float32)
+        b, n, m = xyz1.shape[0], xyz1.shape[1], xyz2.shape[1]
+        d1, i1 = np.empty((b, n), np.float32), np.empty((b, n), np.int32)
+        d2, i2 = np.empty((b, m), np.float32), np.empty((b, m), np.int32)
+        self.lib.ref_nndistance(b, n, self._p(xyz1), m, self._p(xyz2), self._p(d1), self._p(i1), self._p(d2), self._p(i2))
+        return d1, i1, d2, i2
+
+    def nndistancegrad(self, xyz1, xyz2, gd1, i1, gd2, i2):
+        xyz1, xyz2 = np.ascontiguousarray(xyz1, np.float32), np.ascontiguousarray(xyz2, np.float32)
+        gd1, gd2 = np.ascontiguousarray(gd1, np.float32), np.ascontiguousarray(gd2, np.float32)
+        i1, i2 = np.ascontiguousarray(i1, np.int32), np.ascontiguousarray(i2, np.int32)
+        b, n, m = xyz1.shape[0], xyz1.shape[1], xyz2.shape[1]
+        g1, g2 = np.empty((b, n, 3), np.float32), np.empty((b, m, 3), np.float32)
+        self.lib.ref_nndistancegrad(b, n, self._p(xyz1), m, self._p(xyz2), self._p(gd1), self._p(i1),
+                                    self._p(gd2), self._p(i2), self._p(g1), self._p(g2))
+        return g1, g2
+
+    def approxmatch(self, xyz1, xyz2):
+        xyz1, xyz2 = np.ascontiguousarray(xyz1, np.float32), np.ascontiguousarray(xyz2, np.float32)
+        b, n, m = xyz1.shape[0], xyz1.shape[1], xyz2.shape[1]
+        match = np.empty((b, m, n), np.float32)
+        temp = np.empty((b, 2 * (n + m)), np.float32)
+        self.lib.ref_approxmatch(b, n, m, self._p(xyz1), self._p(xyz2), self._p(match), self._p(temp))
+        return match, temp
+
+    def matchcost(self, xyz1, xyz2, match):
+        xyz1, xyz2 = np.ascontiguousarray(xyz1, np.float32), np.ascontiguousarray(xyz2, np.float32)
+        match = np.ascontiguousarray(match, np.float32)
+        b, n, m = xyz1.shape[0], xyz1.shape[1], xyz2.shape[1]
+        out = np.empty((b,), np.float32)
+        self.lib.ref_matchcost(b, n, m, self._p(xyz1), self._p(xyz2), self._p(match), self._p(out))
+        return out
+
+    def matchcostgrad(self, xyz1, xyz2, match):
+        xyz1, xyz2 = np.ascontiguousarray(xyz1, np.float32), np.ascontiguousarray(xyz2, np.float32)
+        match = np.ascontiguousarray(match, np.float32)
+        b, n, m = xyz1.shape[0], xyz1.shape[1], xyz2.shape[1]
+        g1, g2 = np.empty((b, n, 3), np.float32), np.empty((b, m, 3), np.float32)
+        self.lib.ref_matchcostgrad(b, n, m, self._p(xyz1), self._p(xyz2), self._p(match), self._p(g1), self._p(g2))
+        return g1, g2
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    return OracleLib()
+
+
+@pytest.fixture(scope="session")
+def ref():
+    """The torch-CPU restatement of the model step (oracle/hyperpocket_ref.py)."""
+    from oracle import hyperpocket_ref
+    return hyperpocket_ref

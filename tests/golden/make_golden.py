@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by IMPORTING THE REFERENCE.
+
+Run only in the build container (needs /root/reference, CPU only):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Nothing here travels to the GPU box except the .npz files it writes.  The fixtures hold
+data only: inputs, captured random draws and the reference's outputs.
+
+What is pinned (reference file:line)
+  chamfer_small / chamfer_2048 : losses/champfer_loss.py:11-35 (value, min dists, arg-mins,
+                                 autograd gradients)
+  points_*                     : utils/points.py:8-36 (exact draws for a seeded CPU RNG)
+  model_small                  : model/full_model.py:54-80 + encoder/hyper_network/
+                                 target_network (rec, mu, exp(logvar), per-cloud weight
+                                 vectors, loss, parameter-gradient statistics)
+  train_steps                  : core/epoch_loops.py:8-46 driven for 3 steps with Adam
+                                 (core/main.py:62-66 hyper-parameters)
+`weights_init` / `seed_setup` (core/setup.py:12-19,63-77) cannot be imported (circular
+import through utils.util -> datasets) and are restated below.
+"""
+import copy
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = os.environ.get("HP_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+
+from losses.champfer_loss import ChamferLoss  # noqa: E402
+from model.full_model import FullModel  # noqa: E402
+import model.full_model as ref_full_model  # noqa: E402
+from utils.points import generate_points  # noqa: E402
+from core.epoch_loops import train_epoch  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def weights_init(m):  # core/setup.py:63-77
+    classname = m.__class__.__name__
+    if classname.find('Conv') != -1 or classname.find('Linear') != -1:
+        gain = torch.nn.init.calculate_gain('relu')
+        torch.nn.init.xavier_uniform_(m.weight, gain)
+        if m.bias is not None:
+            torch.nn.init.constant_(m.bias, 0)
+
+
+def model_config(random_out=128, real_out=128):  # settings/config_3depn_airplane.json.sample:72-103
+    return {
+        "random_encoder": {"output_size": random_out, "use_bias": True, "relu_slope": 0.2},
+        "real_encoder": {"output_size": real_out, "use_bias": True, "relu_slope": 0.2},
+        "hyper_network": {"use_bias": True, "relu_slope": 0.2},
+        "target_network": {"use_bias": True, "relu_slope": 0.2, "freeze_layers_learning": False,
+                           "layer_out_channels": [32, 64, 128, 64]},
+        "target_network_input": {"constant": False,
+                                 "normalization": {"enable": True, "type": "progressive", "epoch": 100}},
+    }
+
+
+def f32(t):
+    return t.detach().cpu().numpy().astype(np.float32)
+
+
+def chamfer_fixtures():
+    loss = ChamferLoss()
+    for name, (b, n, m, seed) in {"chamfer_small": (3, 64, 48, 11), "chamfer_2048": (4, 2048, 2048, 12),
+                                  "chamfer_ragged": (2, 37, 130, 13)}.items():
+        g = torch.Generator().manual_seed(seed)
+        preds = (torch.rand(b, n, 3, generator=g) - 0.5).requires_grad_(True)
+        gts = (torch.rand(b, m, 3, generator=g) - 0.5).requires_grad_(True)
+        # ChamferLoss.forward(preds, gts): P = batch_pairwise_dist(gts, preds) -> (b, m, n)
+        P = loss.batch_pairwise_dist(gts, preds)
+        min_over_gts, arg_over_gts = torch.min(P, 1)   # per pred point: nearest gt
+        min_over_preds, arg_over_preds = torch.min(P, 2)  # per gt point: nearest pred
+        value = loss(preds, gts)
+        value.backward()
+        np.savez(os.path.join(OUT, name + ".npz"),
+                 preds=f32(preds), gts=f32(gts), value=f32(value),
+                 dist_pred=f32(min_over_gts), idx_pred=arg_over_gts.numpy().astype(np.int32),
+                 dist_gt=f32(min_over_preds), idx_gt=arg_over_preds.numpy().astype(np.int32),
+                 grad_preds=f32(preds.grad), grad_gts=f32(gts.grad))
+        print(name, float(value))
+
+
+def points_fixtures():
+    cfg = {"target_network_input": model_config()["target_network_input"]}
+    out = {}
+    for seed, epoch in [(5, 1), (6, 37), (7, 100), (8, 250)]:
+        torch.manual_seed(seed)
+        p = generate_points(config=cfg, epoch=epoch, size=(2048, 3))
+        out[f"seed{seed}_epoch{epoch}"] = f32(p)
+    torch.manual_seed(9)
+    out["seed9_nonorm"] = f32(generate_points(config=cfg, epoch=1, size=(512, 3), normalize_points=False))
+    np.savez(os.path.join(OUT, "points.npz"), **out)
+    print("points", {k: v.shape for k, v in out.items()})
+
+
+class Recorder:
+    """Captures decoder points (utils/points.py via model/full_model.py:72) and VAE eps
+    (model/encoder.py:40) as the reference draws them."""
+
+    def __init__(self):
+        self.points, self.eps = [], []
+        self._gp = ref_full_model.generate_points
+        self._rl = torch.randn_like
+
+    def __enter__(self):
+        def gp(*a, **k):
+            p = self._gp(*a, **k)
+            self.points.append(p.clone())
+            return p
+
+        def rl(t, *a, **k):
+            e = self._rl(t, *a, **k)
+            self.eps.append(e.clone())
+            return e
+        ref_full_model.generate_points = gp
+        torch.randn_like = rl
+        return self
+
+    def __exit__(self, *a):
+        ref_full_model.generate_points = self._gp
+        torch.randn_like = self._rl
+
+
+def param_stats(model, rng_idx):
+    stats = {}
+    for name, p in model.named_parameters():
+        g = p.grad
+        key = name.replace(".", "__")
+        if g is None:
+            stats["gnone__" + key] = np.zeros(0, np.float32)
+            continue
+        g = g.detach().flatten().double()
+        stats["gnorm__" + key] = np.array([g.norm().item(), g.sum().item()], np.float64)
+        if g.numel() <= 4096:
+            stats["gfull__" + key] = g.float().numpy()
+        else:
+            idx = rng_idx.randint(0, g.numel(), size=1024)
+            stats["gidx__" + key] = idx.astype(np.int64)
+            stats["gsamp__" + key] = g[torch.from_numpy(idx)].float().numpy()
+    return stats
+
+
+def weight_checksums(model):
+    return {"w__" + n.replace(".", "__"): np.array([p.detach().double().sum().item(),
+                                                     p.detach().double().norm().item()], np.float64)
+            for n, p in model.named_parameters()}
+
+
+def model_fixture(name, random_out, real_out, b, n_exist, n_gt, seed, epoch):
+    cfg = model_config(random_out, real_out)
+    torch.manual_seed(seed)
+    model = FullModel(copy.deepcopy(cfg))
+    model.apply(weights_init)
+    model.train()
+    g = torch.Generator().manual_seed(seed + 1)
+    existing = torch.rand(b, n_exist, 3, generator=g) - 0.5
+    if random_out > 0 and real_out > 0:
+        missing = torch.rand(b, n_gt - n_exist, 3, generator=g) - 0.5
+        gt = torch.cat([existing, missing], 1)
+    else:
+        missing = torch.zeros(b)  # Completion3D collates int 0 (datasets/shapenet_completion3d.py:41-48)
+        gt = torch.rand(b, n_gt, 3, generator=g) - 0.5
+    ex_in, mi_in = existing.clone(), missing.clone()
+    gt_shape = list(gt.shape)
+    torch.manual_seed(seed + 2)
+    with Recorder() as rec:
+        out = model(ex_in, mi_in, gt_shape, epoch, torch.device("cpu"))
+    reconstruction, logvar, mu = out
+    loss_r = torch.mean(0.05 * ChamferLoss()(gt, reconstruction.permute(0, 2, 1)))
+    data = dict(existing=f32(existing), gt=f32(gt), rec=f32(reconstruction),
+                points=np.stack([f32(p) for p in rec.points]),
+                loss_r=f32(loss_r), seed=np.array(seed), epoch=np.array(epoch),
+                random_out=np.array(random_out), real_out=np.array(real_out))
+    if missing.dim() == 3:
+        data["missing"] = f32(missing)
+    if model.mode.has_generativity():
+        loss_kld = 0.5 * (torch.exp(logvar) + torch.square(mu) - 1 - logvar).sum()
+        loss_kld = torch.div(loss_kld, existing.shape[0])
+        loss_all = loss_r + loss_kld
+        data.update(loss_kld=f32(loss_kld), mu=f32(mu), explv=f32(logvar), eps=f32(rec.eps[0]))
+    elif mu is not None:  # HyperCloud: VAE outputs returned, no KLD in the loss (full_model.py:136-152)
+        loss_all = loss_r
+        data.update(mu=f32(mu), explv=f32(logvar), eps=f32(rec.eps[0]))
+    else:
+        loss_all = loss_r
+    data["loss_all"] = f32(loss_all)
+    # per-cloud target-network weight vectors (model/full_model.py:67)
+    with torch.no_grad():
+        model.eval()
+        if random_out > 0 and real_out > 0:
+            z = torch.from_numpy(data["eps"]) * torch.from_numpy(data["explv"]) + torch.from_numpy(data["mu"])
+            real_mu = model.real_encoder(existing.transpose(1, 2).contiguous())
+            latent = torch.cat([z, real_mu], 1)
+        elif real_out > 0:
+            latent = model.real_encoder(existing.transpose(1, 2).contiguous())
+        else:
+            latent = torch.from_numpy(data["eps"]) * torch.from_numpy(data["explv"]) + torch.from_numpy(data["mu"])
+        data["latent"] = f32(latent)
+        data["theta"] = f32(model.hyper_network(latent))
+        model.train()
+    loss_all.backward()
+    data.update(param_stats(model, np.random.RandomState(1234)))
+    data.update(weight_checksums(model))
+    # side effects: caller's tensors are transposed in place, gt_shape list mutated
+    data["ex_in_shape_after"] = np.array(ex_in.shape)
+    data["ex_in_stride_after"] = np.array(ex_in.stride())
+    data["gt_shape_after"] = np.array(gt_shape)
+    np.savez(os.path.join(OUT, name + ".npz"), **data)
+    print(name, "loss_all", float(loss_all), "n_arrays", len(data))
+
+
+def train_steps_fixture():
+    """core/epoch_loops.py:8-46 driven with a list loader: 3 steps, Adam(lr 1e-4)."""
+    seed, b, n_half, epoch = 2020, 2, 64, 3
+    cfg = model_config()
+    torch.manual_seed(seed)
+    model = FullModel(copy.deepcopy(cfg))
+    model.apply(weights_init)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=0, betas=(0.9, 0.999), amsgrad=False)
+    g = torch.Generator().manual_seed(seed + 1)
+    batches = []
+    for _ in range(3):
+        ex = torch.rand(b, n_half, 3, generator=g) - 0.5
+        mi = torch.rand(b, n_half, 3, generator=g) - 0.5
+        batches.append((ex, mi, torch.cat([ex, mi], 1), 0))
+    data = {"seed": np.array(seed), "epoch": np.array(epoch)}
+    for s, (ex, mi, gt, _) in enumerate(batches):
+        data[f"existing{s}"], data[f"missing{s}"] = f32(ex), f32(mi)
+    # one train_epoch call per step so that per-step losses can be read back
+    torch.manual_seed(seed + 2)
+    for s, batch in enumerate(batches):
+        loader = [tuple(t.clone() if torch.is_tensor(t) else t for t in batch)]
+        with Recorder() as rec:
+            _, _, loss_all, loss_kld, loss_r, _, _, recon = train_epoch(
+                epoch, model, opt, loader, torch.device("cpu"), ChamferLoss(), 0.05)
+        # train_epoch doubles the last batch's losses (epoch_loops.py:32-36: x += x.item()) and divides by i=1
+        data[f"loss_all{s}"] = np.float32(float(loss_all) / 2)
+        data[f"loss_kld{s}"] = np.float32(float(loss_kld) / 2)
+        data[f"loss_r{s}"] = np.float32(float(loss_r) / 2)
+        data[f"points{s}"] = np.stack([f32(p) for p in rec.points])
+        data[f"eps{s}"] = f32(rec.eps[0])
+        data[f"rec{s}"] = recon.astype(np.float32)
+        for n_, p in model.named_parameters():
+            data[f"psum{s}__" + n_.replace(".", "__")] = np.array(
+                [p.detach().double().sum().item(), p.detach().double().norm().item()], np.float64)
+    np.savez(os.path.join(OUT, "train_steps.npz"), **data)
+    print("train_steps", [float(data[f"loss_all{s}"]) for s in range(3)])
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    chamfer_fixtures()
+    points_fixtures()
+    model_fixture("model_small", 128, 128, 2, 96, 192, 1856, 1)      # HyperPocket
+    model_fixture("model_small_e60", 128, 128, 3, 50, 120, 77, 60)   # HyperPocket, ragged sizes, epoch 60
+    model_fixture("model_hyperrec", 0, 128, 2, 160, 160, 2020, 120)  # HyperRec (Completion3D config)
+    model_fixture("model_hypercloud", 128, 0, 2, 96, 96, 31, 10)     # HyperCloud
+    train_steps_fixture()
+    meta = {"torch": torch.__version__, "numpy": np.__version__, "reference": REF}
+    json.dump(meta, open(os.path.join(OUT, "META.json"), "w"), indent=1)
