@@ -1,0 +1,181 @@
+// Auxiliary kernels of the training step that are neither contractions nor structural losses:
+//   - decoder input sampler        /root/reference/utils/points.py:8-36  (uniform-in-ball points with
+//                                  "progressive normalisation"), drawn ON DEVICE for all B clouds in
+//                                  one launch instead of B CPU draws + B host-to-device copies
+//                                  (model/full_model.py:72-74)
+//   - KLD term                     core/epoch_loops.py:29-30 (forward value and its two gradients)
+//   - Adam                         core/main.py:62-66 -> torch.optim.Adam(lr, betas, eps, wd=0, amsgrad=False)
+#include "hp_common.h"
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+// ---- Philox4x32-10 (Salmon et al. 2011), counter-based: reproducible for a (seed, offset) pair
+__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
+        const uint32_t hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
+        ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+        key.x += W0;
+        key.y += W1;
+    }
+    return ctr;
+}
+
+__device__ __forceinline__ float u01_to_pm1(uint32_t x) {  // [-1, 1): low + (high-low)*u, u in [0,1)
+    return __builtin_fmaf((float)(x >> 8), 2.0f / 16777216.0f, -1.0f);
+}
+
+// One lane per output point: rejection-sample the unit ball (acceptance pi/6), then push points
+// with |p| < coef out to radius coef (utils/points.py:24-33).  Same distribution as the reference's
+// "first N accepted rows of a 3N x 3 uniform(-1,1) draw"; the draws themselves differ (Philox vs
+// the torch CPU generator) — exact reference draws come from the host path in utils/points.py.
+__global__ __launch_bounds__(256) void sample_points_kernel(long total, float coef, unsigned long long seed,
+                                                            unsigned long long offset, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
+    float x = 0.f, y = 0.f, z = 0.f, n2 = 4.f;
+    for (uint32_t attempt = 0; attempt < 64 && !(n2 < 1.0f); ++attempt) {
+        const uint4 r = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)((unsigned long long)i >> 32) ^ (attempt << 8),
+                                                 (uint32_t)offset, (uint32_t)(offset >> 32)), key);
+        x = u01_to_pm1(r.x);
+        y = u01_to_pm1(r.y);
+        z = u01_to_pm1(r.z);
+        n2 = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
+    }
+    if (!(n2 < 1.0f)) { x = y = z = 0.f; n2 = 0.f; }  // 2^-64 event; keeps the contract |p| < 1
+    const float nrm = __builtin_sqrtf(n2);
+    if (nrm < coef) {
+        if (nrm > 0.f) {
+            const float s = coef / nrm;
+            x *= s; y *= s; z *= s;
+        } else {
+            x = coef; y = 0.f; z = 0.f;
+        }
+    }
+    out[i * 3 + 0] = x;
+    out[i * 3 + 1] = y;
+    out[i * 3 + 2] = z;
+}
+
+// KLD = 0.5 * sum(exp(v) + mu^2 - 1 - v) / B with v = the encoder's exp(logvar) output
+// single block: ordered double accumulation; also writes the two gradients scaled by `gscale`
+__global__ __launch_bounds__(256) void kld_kernel(long n, float inv_b, const float* __restrict__ v, const float* __restrict__ mu,
+                                                  float* __restrict__ out) {
+    __shared__ double red[4];
+    double s = 0;
+    for (long t = threadIdx.x; t < n; t += 256) {
+        const float a = v[t], m = mu[t];
+        s += (double)(expf(a) + m * m - 1.0f - a);
+    }
+    const double tot = hp::block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = (float)(0.5 * tot * (double)inv_b);
+}
+
+__global__ __launch_bounds__(256) void kld_grad_kernel(long n, float inv_b, const float* __restrict__ v, const float* __restrict__ mu,
+                                                       const float* __restrict__ gout, float* __restrict__ gv,
+                                                       float* __restrict__ gmu) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const float g = gout[0] * inv_b;
+    gv[t] = 0.5f * g * (expf(v[t]) - 1.0f);
+    gmu[t] = g * mu[t];
+}
+
+// torch.optim.Adam single-tensor update, fused: 4 streams in, 3 out, 16 B per lane
+__global__ __launch_bounds__(256) void adam_kernel(long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, float b1, float b2, float eps, float step_size,
+                                                   float inv_sqrt_bc2, float grad_scale) {
+    const long stride = (long)gridDim.x * 256 * 4;
+    for (long t = ((long)blockIdx.x * 256 + threadIdx.x) * 4; t < n; t += stride) {
+        if (t + 3 < n) {
+            float4 pp = *reinterpret_cast<float4*>(p + t);
+            float4 gg = *reinterpret_cast<const float4*>(g + t);
+            float4 mm = *reinterpret_cast<float4*>(m + t);
+            float4 vv = *reinterpret_cast<float4*>(v + t);
+            float* pa = &pp.x; float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gr = ga[e] * grad_scale;
+                ma[e] = b1 * ma[e] + (1.0f - b1) * gr;
+                va[e] = b2 * va[e] + (1.0f - b2) * gr * gr;
+                const float denom = __builtin_sqrtf(va[e]) * inv_sqrt_bc2 + eps;
+                pa[e] = pa[e] - step_size * (ma[e] / denom);
+            }
+            *reinterpret_cast<float4*>(p + t) = pp;
+            *reinterpret_cast<float4*>(m + t) = mm;
+            *reinterpret_cast<float4*>(v + t) = vv;
+        } else {
+            for (long u = t; u < n; ++u) {
+                const float gr = g[u] * grad_scale;
+                const float mn = b1 * m[u] + (1.0f - b1) * gr;
+                const float vn = b2 * v[u] + (1.0f - b2) * gr * gr;
+                m[u] = mn;
+                v[u] = vn;
+                p[u] = p[u] - step_size * (mn / (__builtin_sqrtf(vn) * inv_sqrt_bc2 + eps));
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// Decoder input points for `total` = B*N points: out (B,N,3).  coef = progressive-normalisation
+// radius (utils/points.py:21-23): linspace(0,1,E)[epoch-1] for epoch<=E else 1; 0 disables it.
+HP_API int hp_sample_points(long total, float coef, unsigned long long seed, unsigned long long offset, float* out,
+                            hipStream_t stream) {
+    HP_CHECK_ARG(total >= 0 && out);
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(sample_points_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, total, coef, seed, offset,
+                       out);
+    HP_RETURN_LAST_ERROR();
+}
+
+// core/epoch_loops.py:29-30
+HP_API int hp_kld_forward(long n, int batch, const float* explv, const float* mu, float* out, hipStream_t stream) {
+    HP_CHECK_ARG(n > 0 && batch > 0 && explv && mu && out);
+    hipLaunchKernelGGL(kld_kernel, dim3(1), dim3(256), 0, stream, n, 1.0f / (float)batch, explv, mu, out);
+    HP_RETURN_LAST_ERROR();
+}
+
+HP_API int hp_kld_backward(long n, int batch, const float* explv, const float* mu, const float* grad_out, float* grad_explv,
+                           float* grad_mu, hipStream_t stream) {
+    HP_CHECK_ARG(n > 0 && batch > 0 && explv && mu && grad_out && grad_explv && grad_mu);
+    hipLaunchKernelGGL(kld_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, 1.0f / (float)batch, explv, mu,
+                       grad_out, grad_explv, grad_mu);
+    HP_RETURN_LAST_ERROR();
+}
+
+// One Adam step over a contiguous run of n parameters (step = 1-based step count).
+// grad_scale multiplies the gradient first (1 for the reference's semantics).
+HP_API int hp_adam_step(long n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2, float eps,
+                        int step, float grad_scale, hipStream_t stream) {
+    HP_CHECK_ARG(n >= 0 && step >= 1);
+    if (n == 0) return 0;
+    HP_CHECK_ARG(p && g && m && v);
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    const bool al = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+    if (!al) {  // unaligned views: peel to scalar path by launching with n small chunks is overkill; use 1-wide lanes
+        // process the unaligned head (< 4 elements) on a tiny launch, then the aligned body
+        const long head = std::min<long>(n, (4 - (((uintptr_t)p >> 2) & 3)) & 3);
+        const bool same = ((((uintptr_t)p ^ (uintptr_t)g) | ((uintptr_t)p ^ (uintptr_t)m) | ((uintptr_t)p ^ (uintptr_t)v)) & 15) == 0;
+        if (!same) return -1;  // the four streams must share their 16-byte phase
+        if (head) {
+            hipLaunchKernelGGL(adam_kernel, dim3(1), dim3(256), 0, stream, head, p, g, m, v, beta1, beta2, eps, step_size,
+                               inv_sqrt_bc2, grad_scale);
+            p += head; g += head; m += head; v += head; n -= head;
+            if (n == 0) HP_RETURN_LAST_ERROR();
+        }
+    }
+    const long groups = (n + 3) / 4;
+    const unsigned blocks = (unsigned)std::min<long>((groups + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, n, p, g, m, v, beta1, beta2, eps, step_size, inv_sqrt_bc2,
+                       grad_scale);
+    HP_RETURN_LAST_ERROR();
+}

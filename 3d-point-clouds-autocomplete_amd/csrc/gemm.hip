@@ -1,0 +1,315 @@
+// fp32 matrix-core GEMM for gfx950 (v_mfma_f32_32x32x2_f32: exact f32, k-ordered fma chain).
+//
+// One kernel family serves every dense contraction of the HyperPocket step:
+//   encoder 1x1-conv stacks      /root/reference/model/encoder.py:14-28      (X W^T + b, ReLU)
+//   encoder fc / mu / std heads  model/encoder.py:30-36
+//   hypernetwork trunk + heads   model/hyper_network.py:16-43
+//   target-network layers        model/target_network.py:31-38 (batched: one weight set per cloud)
+//   and all their backward contractions (dX = dZ W, dW = dZ^T X), which the reference gets from
+//   autograd over cuBLAS.
+//
+//   C[z](i,j) = epi( sum_k A[z](i,k) * B[z](k,j) ),  z = 0..batch-1
+//   A(i,k) at A + z*sAz + i*sAi + k*sAk ; B(k,j) at B + z*sBz + k*sBk + j*sBj ; C row-major, ldc.
+//   Either stride of an operand may be the unit one: a "K-contiguous" operand is fetched with
+//   16-byte loads along k, an "i/j-contiguous" one with lane-coalesced loads along i/j.  Both land
+//   in the same LDS image ([row][k], 80-byte rows: conflict-free ds_read_b128 fragment reads), so
+//   the MFMA loop is layout-agnostic.
+//   epi: + bias[j] -> ReLU -> * (mask(i,j) > 0)    (each optional; mask = stored post-ReLU
+//        activation, i.e. the ReLU backward fused into the producing GEMM).
+//   Split-K (ksplit > 1): partial slabs in `ws`, combined in split order by a second kernel that
+//   applies the epilogue — ordered and atomic-free, so results are run-to-run identical.
+//
+// Workgroup = 4 waves; a wave owns TMxTN tiles of 32x32 (f32x16 accumulators); BK = 16.
+// Tile ids are remapped so that the 8 XCDs each get a contiguous run of tiles (neighbouring
+// tiles share an A or B panel in that XCD's L2).
+#include "hp_common.h"
+#include "hp_gemm.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;
+constexpr int LDK = 20;  // padded LDS row (floats): 80 B keeps 16-B alignment, b128 reads conflict-free
+
+struct KParams {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    const float* mask;
+    const float* add;
+    float* ws;
+    long sAz, sBz, sCz, sBiasz, sMaskz, sAddz;
+    long sAi, sAk, sBk, sBj;
+    int ldc, ldmask, ldadd;
+    int M, N, K;
+    int ksplit, kchunk;
+    int flags;
+    int vecA, vecB;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ float4 ld4(const float* __restrict__ base, long rowoff, int k, long s_k, bool row_ok, int kend, bool vec) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!row_ok) return v;
+    const float* p = base + rowoff + (long)k * s_k;
+    if (vec && k + 3 < kend) {
+        v = *reinterpret_cast<const float4*>(p);
+    } else {
+        if (k < kend) v.x = p[0];
+        if (k + 1 < kend) v.y = p[s_k];
+        if (k + 2 < kend) v.z = p[2 * s_k];
+        if (k + 3 < kend) v.w = p[3 * s_k];
+    }
+    return v;
+}
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const KParams p) {
+    constexpr int NT = WGM * WGN * 64;
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
+    constexpr int NA = (BM * 4 + NT - 1) / NT, NB = (BN * 4 + NT - 1) / NT;
+    static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
+    __shared__ __attribute__((aligned(16))) float As[BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
+
+    // XCD-aware bijective remap of the tile id (cdna_hip_programming.md T1)
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    const int z = blockIdx.y / p.ksplit, split = blockIdx.y - z * p.ksplit;
+    const int row0 = tile_m * BM, col0 = tile_n * BN;
+    const int kbeg = split * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
+
+    const float* A = p.A + (long)z * p.sAz;
+    const float* B = p.B + (long)z * p.sBz;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int r = lane & 31, h = lane >> 5;
+    const bool a_kc = (p.sAk == 1), b_kc = (p.sBk == 1);
+
+    // staging assignment: each thread moves NA (NB) groups of 4 consecutive k of one row
+    int a_row[NA], a_kq[NA], b_row[NB], b_kq[NB];
+#pragma unroll
+    for (int e = 0; e < NA; ++e) {
+        const int idx = tid + e * NT;
+        a_row[e] = a_kc ? (idx >> 2) : (idx % BM);
+        a_kq[e] = a_kc ? (idx & 3) : (idx / BM);
+    }
+#pragma unroll
+    for (int e = 0; e < NB; ++e) {
+        const int idx = tid + e * NT;
+        b_row[e] = b_kc ? (idx >> 2) : (idx % BN);
+        b_kq[e] = b_kc ? (idx & 3) : (idx / BN);
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    float4 ra[NA], rb[NB];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < NA; ++e) {
+            const int row = row0 + a_row[e];
+            const bool ok = (tid + e * NT < BM * 4) && row < p.M;
+            ra[e] = ld4(A, (long)row * p.sAi, k0 + a_kq[e] * 4, p.sAk, ok, kend, p.vecA);
+        }
+#pragma unroll
+        for (int e = 0; e < NB; ++e) {
+            const int col = col0 + b_row[e];
+            const bool ok = (tid + e * NT < BN * 4) && col < p.N;
+            rb[e] = ld4(B, (long)col * p.sBj, k0 + b_kq[e] * 4, p.sBk, ok, kend, p.vecB);
+        }
+    };
+
+    if (kbeg < kend) fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+#pragma unroll
+        for (int e = 0; e < NA; ++e)
+            if (tid + e * NT < BM * 4) *reinterpret_cast<float4*>(&As[a_row[e] * LDK + a_kq[e] * 4]) = ra[e];
+#pragma unroll
+        for (int e = 0; e < NB; ++e)
+            if (tid + e * NT < BN * 4) *reinterpret_cast<float4*>(&Bs[b_row[e] * LDK + b_kq[e] * 4]) = rb[e];
+        __syncthreads();
+        if (k0 + BK < kend) fetch(k0 + BK);  // next tile's global loads fly under this tile's MFMAs
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = *reinterpret_cast<const float4*>(&As[(wm * WM + i * 32 + r) * LDK + 8 * t + 4 * h]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[j] = *reinterpret_cast<const float4*>(&Bs[(wn * WN + j * 32 + r) * LDK + 8 * t + 4 * h]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float av = s == 0 ? a[i].x : (s == 1 ? a[i].y : (s == 2 ? a[i].z : a[i].w));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float bv = s == 0 ? b[j].x : (s == 1 ? b[j].y : (s == 2 ? b[j].z : b[j].w));
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue.  C/D map of the 32x32 f32 tile: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    const bool partial = p.ksplit > 1;
+    float* C = partial ? p.ws + ((long)blockIdx.y) * p.M * p.N : p.C + (long)z * p.sCz;
+    const int ldc = partial ? p.N : p.ldc;
+    const float* bias = (p.flags & HP_GEMM_BIAS) ? p.bias + (long)z * p.sBiasz : nullptr;
+    const float* mask = (p.flags & HP_GEMM_MASK) ? p.mask + (long)z * p.sMaskz : nullptr;
+    const float* add = (p.flags & HP_GEMM_ADD) ? p.add + (long)z * p.sAddz : nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = col0 + wn * WN + j * 32 + r;
+            if (col >= p.N) continue;
+            const float bv = (!partial && bias) ? bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = row0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row >= p.M) continue;
+                float v = acc[i][j][e];
+                if (!partial) {
+                    v += bv;
+                    if (add) v += add[(long)row * p.ldadd + col];
+                    if (p.flags & HP_GEMM_RELU) v = fmaxf(v, 0.f);
+                    if (mask) v = (mask[(long)row * p.ldmask + col] > 0.f) ? v : 0.f;
+                }
+                C[(long)row * ldc + col] = v;
+            }
+        }
+    }
+}
+
+// C = epi(sum_s ws[z][s]) in split order
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams p) {
+    const long mn = (long)p.M * p.N;
+    const int z = blockIdx.y;
+    const float* bias = (p.flags & HP_GEMM_BIAS) ? p.bias + (long)z * p.sBiasz : nullptr;
+    const float* mask = (p.flags & HP_GEMM_MASK) ? p.mask + (long)z * p.sMaskz : nullptr;
+    const float* add = (p.flags & HP_GEMM_ADD) ? p.add + (long)z * p.sAddz : nullptr;
+    float* C = p.C + (long)z * p.sCz;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < mn; t += (long)gridDim.x * 256) {
+        const float* w = p.ws + (long)z * p.ksplit * mn + t;
+        float v = 0.f;
+        for (int s = 0; s < p.ksplit; ++s) v += w[(long)s * mn];
+        const int row = (int)(t / p.N), col = (int)(t - (long)row * p.N);
+        if (bias) v += bias[col];
+        if (add) v += add[(long)row * p.ldadd + col];
+        if (p.flags & HP_GEMM_RELU) v = fmaxf(v, 0.f);
+        if (mask) v = (mask[(long)row * p.ldmask + col] > 0.f) ? v : 0.f;
+        C[(long)row * p.ldc + col] = v;
+    }
+}
+
+// out[z][j] = sum_i X[z](i,j)  (bias gradients).  One workgroup per 64 columns x row-slab, ordered.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long sXz, int ldx, int M, int N,
+                                                     const float* __restrict__ mask, long sMaskz, int ldmask,
+                                                     float* __restrict__ out, long sOz) {
+    __shared__ float red[4][64];
+    const int z = blockIdx.y;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int w = threadIdx.x >> 6;
+    const float* x = X + (long)z * sXz;
+    const float* mk = mask ? mask + (long)z * sMaskz : nullptr;
+    float s = 0.f;
+    if (c < N) {
+        for (int i = w; i < M; i += 4) {
+            float v = x[(long)i * ldx + c];
+            if (mk) v = (mk[(long)i * ldmask + c] > 0.f) ? v : 0.f;
+            s += v;
+        }
+    }
+    red[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && c < N) out[(long)z * sOz + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+template <int BM, int BN, int WGM, int WGN>
+int launch_cfg(KParams& p, int batch, hipStream_t stream) {
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    dim3 grid(p.tiles_m * p.tiles_n, batch * p.ksplit);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN>), grid, dim3(WGM * WGN * 64), 0, stream, p);
+    return (int)hipGetLastError();
+}
+
+inline bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+}  // namespace
+
+HP_API long hp_gemm_workspace_floats(const HpGemmDesc* d) {
+    if (!d || d->ksplit <= 1) return 0;
+    return (long)d->batch * d->ksplit * d->M * d->N;
+}
+
+HP_API int hp_gemm_f32(const HpGemmDesc* d, hipStream_t stream) {
+    HP_CHECK_ARG(d && d->M >= 0 && d->N >= 0 && d->K >= 0 && d->batch >= 0);
+    if (d->M == 0 || d->N == 0 || d->batch == 0) return 0;
+    HP_CHECK_ARG(d->A && d->B && d->C);
+    HP_CHECK_ARG(d->sAi == 1 || d->sAk == 1 || d->M == 1 || d->K == 1);
+    HP_CHECK_ARG(d->sBk == 1 || d->sBj == 1 || d->N == 1 || d->K == 1);
+    HP_CHECK_ARG(!(d->flags & HP_GEMM_BIAS) || d->bias);
+    HP_CHECK_ARG(!(d->flags & HP_GEMM_MASK) || d->mask);
+    HP_CHECK_ARG(!(d->flags & HP_GEMM_ADD) || d->add);
+    HP_CHECK_ARG(d->batch * (long)(d->ksplit > 1 ? d->ksplit : 1) <= 65535);
+    KParams p;
+    p.A = d->A; p.B = d->B; p.C = d->C; p.bias = d->bias; p.mask = d->mask; p.add = d->add; p.ws = d->ws;
+    p.sAz = d->sAz; p.sBz = d->sBz; p.sCz = d->sCz; p.sBiasz = d->sBiasz; p.sMaskz = d->sMaskz; p.sAddz = d->sAddz;
+    p.ldadd = d->ldadd;
+    p.sAi = d->sAi; p.sAk = d->sAk; p.sBk = d->sBk; p.sBj = d->sBj;
+    p.ldc = d->ldc; p.ldmask = d->ldmask; p.M = d->M; p.N = d->N; p.K = d->K; p.flags = d->flags;
+    p.ksplit = d->ksplit > 1 ? d->ksplit : 1;
+    p.kchunk = ((d->K + p.ksplit - 1) / p.ksplit + BK - 1) / BK * BK;
+    if (p.kchunk == 0) p.kchunk = BK;
+    // a split whose range is empty still writes its (zero) slab, so every slab is initialised
+    HP_CHECK_ARG(p.ksplit == 1 || d->ws);
+    p.vecA = (d->sAk == 1) && (d->sAi % 4 == 0) && (d->sAz % 4 == 0) && aligned16(d->A);
+    p.vecB = (d->sBk == 1) && (d->sBj % 4 == 0) && (d->sBz % 4 == 0) && aligned16(d->B);
+
+    int rc;
+    const long tilesA = (long)((d->M + 127) / 128) * ((d->N + 127) / 128) * d->batch * p.ksplit;
+    if (d->N <= 32)
+        rc = launch_cfg<128, 32, 4, 1>(p, d->batch, stream);
+    else if (d->M <= 64 && d->N > 64)
+        rc = launch_cfg<64, 128, 2, 2>(p, d->batch, stream);
+    else if (d->M <= 64 || d->N <= 64 || tilesA < 192)
+        rc = launch_cfg<64, 64, 2, 2>(p, d->batch, stream);
+    else
+        rc = launch_cfg<128, 128, 2, 2>(p, d->batch, stream);
+    if (rc) return rc;
+    if (p.ksplit > 1) {
+        const long mn = (long)d->M * d->N;
+        const int blocks = (int)std::min<long>((mn + 255) / 256, 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, d->batch), dim3(256), 0, stream, p);
+    }
+    HP_RETURN_LAST_ERROR();
+}
+
+// Column sums (bias gradients): out[z][j] = sum_i (mask(i,j)>0 ? X(i,j) : 0)
+HP_API int hp_colsum_f32(int batch, int M, int N, const float* X, long sXz, int ldx, const float* mask, long sMaskz,
+                         int ldmask, float* out, long sOz, hipStream_t stream) {
+    HP_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0);
+    if (batch == 0 || N == 0) return 0;
+    HP_CHECK_ARG(batch <= 65535);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, batch), dim3(256), 0, stream, X, sXz, ldx, M, N, mask, sMaskz, ldmask,
+                       out, sOz);
+    HP_RETURN_LAST_ERROR();
+}

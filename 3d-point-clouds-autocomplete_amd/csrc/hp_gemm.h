@@ -1,0 +1,23 @@
+/* GEMM descriptor shared by the C ABI (include/hyperpocket_hip.h repeats it for C callers). */
+#pragma once
+
+#define HP_GEMM_BIAS 1 /* + bias[j]                                   */
+#define HP_GEMM_RELU 2 /* max(., 0)                                   */
+#define HP_GEMM_MASK 4 /* * (mask(i,j) > 0)  — ReLU backward, fused   */
+#define HP_GEMM_ADD 8  /* + add(i,j)  (before ReLU / mask)             */
+
+typedef struct HpGemmDesc {
+    const float* A;    /* A(i,k) at A + z*sAz + i*sAi + k*sAk (one of sAi,sAk is 1) */
+    const float* B;    /* B(k,j) at B + z*sBz + k*sBk + j*sBj (one of sBk,sBj is 1) */
+    float* C;          /* C(i,j) at C + z*sCz + i*ldc + j                           */
+    const float* bias; /* bias(j) at bias + z*sBiasz + j                            */
+    const float* mask; /* mask(i,j) at mask + z*sMaskz + i*ldmask + j               */
+    const float* add;  /* add(i,j) at add + z*sAddz + i*ldadd + j                   */
+    float* ws;         /* split-K slabs: hp_gemm_workspace_floats(desc) floats       */
+    long sAz, sBz, sCz, sBiasz, sMaskz, sAddz;
+    long sAi, sAk, sBk, sBj;
+    int ldc, ldmask, ldadd;
+    int M, N, K, batch;
+    int ksplit; /* <=1: no split */
+    int flags;
+} HpGemmDesc;

@@ -1,0 +1,47 @@
+/* Parameter-pointer tables of the model entry points (mirrored in include/hyperpocket_hip.h). */
+#pragma once
+
+#define HP_MAX_HEADS 8
+#define HP_MAX_TN_LAYERS 8
+
+/* model/encoder.py:14-36 — shapes are fixed by the reference's code: conv 3-64-128-256-512-512,
+ * fc 512x512, mu/std (out,512).  Weights row-major (out,in) exactly as nn.Conv1d(k=1)/nn.Linear
+ * store them. */
+typedef struct HpEncoderWeights {
+    const float* conv_w[5];
+    const float* conv_b[5];
+    const float* fc_w;
+    const float* fc_b;
+    const float* mu_w;
+    const float* mu_b;
+    const float* std_w; /* NULL for a non-VAE encoder */
+    const float* std_b;
+} HpEncoderWeights;
+
+typedef struct HpEncoderGrads {
+    float* conv_w[5];
+    float* conv_b[5];
+    float* fc_w;
+    float* fc_b;
+    float* mu_w;
+    float* mu_b;
+    float* std_w;
+    float* std_b;
+} HpEncoderGrads;
+
+/* model/hyper_network.py:16-36 — trunk in->64->128->512->1024->2048, heads 2048->head_out[h] */
+typedef struct HpHyperWeights {
+    const float* trunk_w[5];
+    const float* trunk_b[5];
+    int n_heads;
+    int head_out[HP_MAX_HEADS];
+    const float* head_w[HP_MAX_HEADS];
+    const float* head_b[HP_MAX_HEADS];
+} HpHyperWeights;
+
+typedef struct HpHyperGrads {
+    float* trunk_w[5];
+    float* trunk_b[5];
+    float* head_w[HP_MAX_HEADS];
+    float* head_b[HP_MAX_HEADS];
+} HpHyperGrads;

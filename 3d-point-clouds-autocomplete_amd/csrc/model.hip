@@ -1,0 +1,481 @@
+// HyperPocket model on gfx950: PointNet encoder, hypernetwork and the batched per-cloud target
+// network, forward and backward, as host-side launch sequences over the fp32-MFMA GEMM family
+// (gemm.hip) plus the small kernels that are not contractions.
+//
+// Replaces (behaviour, not code):
+//   /root/reference/model/encoder.py:14-53         Conv1d(k=1) x5 -> max over points -> fc -> mu/std
+//   /root/reference/model/hyper_network.py:16-43   5-layer trunk + one linear head per target layer
+//   /root/reference/model/target_network.py:6-45   per-cloud MLP whose weights are a slice of theta
+//   /root/reference/model/full_model.py:70-74      the B-iteration Python loop that instantiates one
+//                                                  TargetNetwork per cloud (here: ONE batched launch
+//                                                  per layer, weights addressed by a per-cloud stride)
+// and the autograd graph PyTorch would build for them.
+//
+// Encoder backward uses the exact critical-point sparsity of a PointNet:
+// d/d h5[n,c] is non-zero only at n = argmax_n h5[n,c]; all layers are pointwise, so only the
+// B*512 (cloud, channel) critical rows carry gradient.  Those rows are gathered, their activations
+// recomputed (bit-identical: the GEMM's k-order does not depend on the row), and the backward
+// GEMMs run over B*512 rows instead of B*Np — no activation tensor is kept from the forward.
+#include "hp_common.h"
+#include "hp_gemm.h"
+#include "hp_model.h"
+#include <algorithm>
+
+extern "C" int hp_gemm_f32(const HpGemmDesc* d, hipStream_t stream);
+extern "C" int hp_colsum_f32(int batch, int M, int N, const float* X, long sXz, int ldx, const float* mask, long sMaskz,
+                             int ldmask, float* out, long sOz, hipStream_t stream);
+
+namespace {
+
+constexpr int kEnc[6] = {3, 64, 128, 256, 512, 512};   // model/encoder.py:14-28
+constexpr int kTrunk[5] = {64, 128, 512, 1024, 2048};  // model/hyper_network.py:16-30
+constexpr long kSplitWs = 4L << 20;                    // floats reserved for split-K slabs
+
+#define TRY(x)            \
+    do {                  \
+        int _rc = (x);    \
+        if (_rc) return _rc; \
+    } while (0)
+
+inline long cdiv(long a, long b) { return (a + b - 1) / b; }
+
+// split the contraction when the output alone cannot fill 256 CUs
+int pick_ksplit(int outM, int outN, int kc, int batch) {
+    const long tiles = cdiv(outM, 64) * cdiv(outN, 64) * batch;
+    if (tiles >= 256 || kc < 256) return 1;
+    long ks = std::min<long>(cdiv(512, tiles), kc / 128);
+    ks = std::max<long>(1, std::min<long>(ks, 64));
+    while (ks > 1 && (long)outM * outN * batch * ks > kSplitWs) --ks;
+    return (int)ks;
+}
+
+struct Op {
+    hipStream_t s;
+    float* splitws;
+    // Y(MxN, ldy) = act(X(MxK, ldx) W(NxK)^T + b)        [batched: strides in floats, 0 = shared]
+    int lin_fwd(const float* X, long sXz, int ldx, const float* W, long sWz, const float* b, long sbz, float* Y, long sYz,
+                int ldy, int M, int N, int K, int batch, bool relu) const {
+        HpGemmDesc d{};
+        d.A = X; d.sAz = sXz; d.sAi = ldx; d.sAk = 1;
+        d.B = W; d.sBz = sWz; d.sBk = 1; d.sBj = K;
+        d.C = Y; d.sCz = sYz; d.ldc = ldy;
+        d.bias = b; d.sBiasz = sbz;
+        d.M = M; d.N = N; d.K = K; d.batch = batch;
+        d.flags = (b ? HP_GEMM_BIAS : 0) | (relu ? HP_GEMM_RELU : 0);
+        return hp_gemm_f32(&d, s);
+    }
+    // dX(MxK, ldx) = [add +] dY(MxN, ldy) W(NxK), optionally * (mask > 0)
+    int lin_dx(const float* dY, long sdYz, int ldy, const float* W, long sWz, float* dX, long sdXz, int ldx, int M, int N,
+               int K, int batch, const float* mask, long sMz, int ldm, const float* add, int ldadd) const {
+        HpGemmDesc d{};
+        d.A = dY; d.sAz = sdYz; d.sAi = ldy; d.sAk = 1;
+        d.B = W; d.sBz = sWz; d.sBk = K; d.sBj = 1;
+        d.C = dX; d.sCz = sdXz; d.ldc = ldx;
+        d.mask = mask; d.sMaskz = sMz; d.ldmask = ldm;
+        d.add = add; d.sAddz = sdXz; d.ldadd = ldadd;
+        d.M = M; d.N = K; d.K = N; d.batch = batch;
+        d.flags = (mask ? HP_GEMM_MASK : 0) | (add ? HP_GEMM_ADD : 0);
+        d.ksplit = pick_ksplit(M, K, N, batch);
+        d.ws = splitws;
+        return hp_gemm_f32(&d, s);
+    }
+    // dW(NxK) = dY(MxN, ldy)^T X(MxK, ldx)     (contraction over the M rows)
+    int lin_dw(const float* dY, long sdYz, int ldy, const float* X, long sXz, int ldx, float* dW, long sdWz, int M, int N,
+               int K, int batch) const {
+        HpGemmDesc d{};
+        d.A = dY; d.sAz = sdYz; d.sAi = 1; d.sAk = ldy;
+        d.B = X; d.sBz = sXz; d.sBk = ldx; d.sBj = 1;
+        d.C = dW; d.sCz = sdWz; d.ldc = K;
+        d.M = N; d.N = K; d.K = M; d.batch = batch;
+        d.ksplit = pick_ksplit(N, K, M, batch);
+        d.ws = splitws;
+        return hp_gemm_f32(&d, s);
+    }
+    int colsum(const float* X, long sXz, int ldx, int M, int N, int batch, float* out, long sOz) const {
+        return hp_colsum_f32(batch, M, N, X, sXz, ldx, nullptr, 0, 0, out, sOz, s);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// small kernels
+// ---------------------------------------------------------------------------------------------
+
+// g[b,c] = max_n h[b,n,c], arg[b,c] = first n attaining it   (model/encoder.py:45 output.max(dim=2))
+__global__ __launch_bounds__(256) void colmax_kernel(const float* __restrict__ h, int Np, int C, float* __restrict__ g,
+                                                     int* __restrict__ arg) {
+    __shared__ float sv[4][64];
+    __shared__ int si[4][64];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float best = -__builtin_inff();
+    int bi = 0;
+    if (c < C) {
+        const float* p = h + (long)b * Np * C + c;
+        const int per = (Np + 3) / 4, n0 = w * per, n1 = min(Np, n0 + per);
+        for (int n = n0; n < n1; ++n) {
+            const float v = p[(long)n * C];
+            if (v > best || n == n0) {
+                best = v;
+                bi = n;
+            }
+        }
+        if (n0 >= n1) best = -__builtin_inff();
+    }
+    sv[w][lane] = best;
+    si[w][lane] = bi;
+    __syncthreads();
+    if (w == 0 && c < C) {
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+            if (sv[q][lane] > best) {  // strict: earlier point wins ties
+                best = sv[q][lane];
+                bi = si[q][lane];
+            }
+        g[(long)b * C + c] = best;
+        arg[(long)b * C + c] = bi;
+    }
+}
+
+// xc[(b,c), :] = x[b, arg[b,c], :]
+__global__ __launch_bounds__(256) void gather_rows3_kernel(const float* __restrict__ x, int Np, const int* __restrict__ arg,
+                                                           long rows, int C, float* __restrict__ xc) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= rows) return;
+    const long b = t / C;
+    const float* s = x + (b * Np + arg[t]) * 3;
+    xc[t * 3 + 0] = s[0];
+    xc[t * 3 + 1] = s[1];
+    xc[t * 3 + 2] = s[2];
+}
+
+// Layer-5 backward on the critical rows (one-hot upstream):
+//   dW5[c,k]       = sum_b dg[b,c] * h4c[(b,c),k]
+//   d4[(b,c),k]    = dg[b,c] * W5[c,k] * (h4c[(b,c),k] > 0)
+__global__ __launch_bounds__(256) void enc_l5_bwd_kernel(int B, int C, int K, const float* __restrict__ dg,
+                                                         const float* __restrict__ W5, const float* __restrict__ h4c,
+                                                         float* __restrict__ dW5, float* __restrict__ d4) {
+    const int c = blockIdx.x;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float w = W5[(long)c * K + k];
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float gbc = dg[(long)b * C + c];
+            const long row = (long)b * C + c;
+            const float hv = h4c[row * K + k];
+            s = __builtin_fmaf(gbc, hv, s);
+            d4[row * K + k] = hv > 0.f ? gbc * w : 0.f;
+        }
+        dW5[(long)c * K + k] = s;
+    }
+}
+
+// VAE head (model/encoder.py:38-41,49-51): z = eps*exp(lv) + mu ; returned "logvar" = exp(lv)
+__global__ __launch_bounds__(256) void vae_head_fwd_kernel(long n, const float* __restrict__ eps, const float* __restrict__ mu,
+                                                           const float* __restrict__ lv, float* __restrict__ z,
+                                                           float* __restrict__ explv) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const float e = expf(lv[t]);   // accurate exp: z and the returned exp(logvar) are parity outputs
+    explv[t] = e;
+    z[t] = __builtin_fmaf(eps[t], e, mu[t]);
+}
+
+// d mu = gz + gmu ; d lv = (gz*eps + gexplv) * exp(lv)
+__global__ __launch_bounds__(256) void vae_head_bwd_kernel(long n, const float* __restrict__ eps, const float* __restrict__ lv,
+                                                           const float* __restrict__ gz, const float* __restrict__ gmu,
+                                                           const float* __restrict__ gexplv, float* __restrict__ dmu,
+                                                           float* __restrict__ dlv) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const float a = gz ? gz[t] : 0.f;
+    dmu[t] = a + (gmu ? gmu[t] : 0.f);
+    dlv[t] = (a * eps[t] + (gexplv ? gexplv[t] : 0.f)) * expf(lv[t]);
+}
+
+long enc_fwd_ws(long B, long Np) { return B * Np * (64 + 128 + 256 + 512 + 512); }
+long enc_bwd_ws(long B, long out) {
+    const long Rc = B * 512;
+    return Rc * 4 + Rc * (64 + 128 + 256 + 512) * 2 + B * (2 * out + 4 * 512) + kSplitWs + 64;
+}
+
+}  // namespace
+
+// =================================================================================================
+// Encoder
+// =================================================================================================
+HP_API long hp_encoder_forward_workspace_floats(int B, int Np) { return enc_fwd_ws(B, Np); }
+HP_API long hp_encoder_backward_workspace_floats(int B, int out_size) { return enc_bwd_ws(B, out_size); }
+
+// model/encoder.py:43-53.  x (B,Np,3) contiguous (the layout as loaded; the reference's in-place
+// transpose to (B,3,Np) is a view change only).  Outputs: argidx/g (B,512), f (B,512), mu (B,out);
+// VAE: lv (raw std_layer output), z, explv (= exp(lv), what the reference returns as "logvar").
+HP_API int hp_encoder_forward(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size, int is_vae,
+                              const float* eps, int* argidx, float* g, float* f, float* mu, float* lv, float* z,
+                              float* explv, float* ws, hipStream_t stream) {
+    HP_CHECK_ARG(B > 0 && Np > 0 && out_size > 0 && x && w && argidx && g && f && mu && ws);
+    HP_CHECK_ARG(!is_vae || (eps && lv && z && explv && w->std_w && w->std_b));
+    HP_CHECK_ARG(B <= 65535);
+    const long R = (long)B * Np;
+    HP_CHECK_ARG(R < (1L << 31));
+    Op op{stream, nullptr};
+    float* h[6];
+    h[0] = nullptr;
+    h[1] = ws;
+    for (int l = 2; l <= 5; ++l) h[l] = h[l - 1] + R * kEnc[l - 1];
+    const float* in = x;
+    for (int l = 1; l <= 5; ++l) {
+        TRY(op.lin_fwd(in, 0, kEnc[l - 1], w->conv_w[l - 1], 0, w->conv_b[l - 1], 0, h[l], 0, kEnc[l], (int)R, kEnc[l],
+                       kEnc[l - 1], 1, l < 5));
+        in = h[l];
+    }
+    hipLaunchKernelGGL(colmax_kernel, dim3(512 / 64, B), dim3(256), 0, stream, h[5], Np, 512, g, argidx);
+    TRY(op.lin_fwd(g, 0, 512, w->fc_w, 0, w->fc_b, 0, f, 0, 512, B, 512, 512, 1, true));
+    TRY(op.lin_fwd(f, 0, 512, w->mu_w, 0, w->mu_b, 0, mu, 0, out_size, B, out_size, 512, 1, false));
+    if (is_vae) {
+        TRY(op.lin_fwd(f, 0, 512, w->std_w, 0, w->std_b, 0, lv, 0, out_size, B, out_size, 512, 1, false));
+        const long n = (long)B * out_size;
+        hipLaunchKernelGGL(vae_head_fwd_kernel, dim3((int)cdiv(n, 256)), dim3(256), 0, stream, n, eps, mu, lv, z, explv);
+    }
+    HP_RETURN_LAST_ERROR();
+}
+
+// Gradients of every encoder parameter.  grad_out: d/d z (VAE) or d/d mu (plain); grad_mu / grad_explv:
+// direct gradients on the VAE's mu / exp(logvar) outputs (KLD term), may be NULL.
+HP_API int hp_encoder_backward(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size, int is_vae,
+                               const float* eps, const int* argidx, const float* g, const float* f, const float* lv,
+                               const float* grad_out, const float* grad_mu, const float* grad_explv,
+                               const HpEncoderGrads* gr, float* ws, hipStream_t stream) {
+    HP_CHECK_ARG(B > 0 && Np > 0 && out_size > 0 && x && w && argidx && g && f && gr && ws);
+    HP_CHECK_ARG(grad_out || grad_mu || grad_explv);
+    HP_CHECK_ARG(!is_vae || (eps && lv));
+    const long Rc = (long)B * 512;
+    float* p = ws;
+    auto take = [&](long n) { float* r = p; p += (n + 3) / 4 * 4; return r; };
+    float* xc = take(Rc * 3);
+    float* hc[5];
+    for (int l = 1; l <= 4; ++l) hc[l] = take(Rc * kEnc[l]);
+    float* dl[5];
+    for (int l = 1; l <= 4; ++l) dl[l] = take(Rc * kEnc[l]);
+    float* dmu = take((long)B * out_size);
+    float* dlv = take((long)B * out_size);
+    float* tmp = take((long)B * 512);
+    float* dfc = take((long)B * 512);
+    float* dg = take((long)B * 512);
+    Op op{stream, take(kSplitWs)};
+
+    // ---- heads (model/encoder.py:46-53)
+    const float* dmu_p;
+    if (is_vae) {
+        const long n = (long)B * out_size;
+        hipLaunchKernelGGL(vae_head_bwd_kernel, dim3((int)cdiv(n, 256)), dim3(256), 0, stream, n, eps, lv, grad_out, grad_mu,
+                           grad_explv, dmu, dlv);
+        dmu_p = dmu;
+        TRY(op.lin_dw(dlv, 0, out_size, f, 0, 512, gr->std_w, 0, B, out_size, 512, 1));
+        TRY(op.colsum(dlv, 0, out_size, B, out_size, 1, gr->std_b, 0));
+        TRY(op.lin_dx(dlv, 0, out_size, w->std_w, 0, tmp, 0, 512, B, out_size, 512, 1, nullptr, 0, 0, nullptr, 0));
+    } else {
+        dmu_p = grad_out;
+    }
+    TRY(op.lin_dw(dmu_p, 0, out_size, f, 0, 512, gr->mu_w, 0, B, out_size, 512, 1));
+    TRY(op.colsum(dmu_p, 0, out_size, B, out_size, 1, gr->mu_b, 0));
+    TRY(op.lin_dx(dmu_p, 0, out_size, w->mu_w, 0, dfc, 0, 512, B, out_size, 512, 1, f, 0, 512, is_vae ? tmp : nullptr, 512));
+    TRY(op.lin_dw(dfc, 0, 512, g, 0, 512, gr->fc_w, 0, B, 512, 512, 1));
+    TRY(op.colsum(dfc, 0, 512, B, 512, 1, gr->fc_b, 0));
+    TRY(op.lin_dx(dfc, 0, 512, w->fc_w, 0, dg, 0, 512, B, 512, 512, 1, nullptr, 0, 0, nullptr, 0));
+
+    // ---- conv stack on the B*512 critical rows
+    hipLaunchKernelGGL(gather_rows3_kernel, dim3((int)cdiv(Rc, 256)), dim3(256), 0, stream, x, Np, argidx, Rc, 512, xc);
+    const float* in = xc;
+    for (int l = 1; l <= 4; ++l) {
+        TRY(op.lin_fwd(in, 0, kEnc[l - 1], w->conv_w[l - 1], 0, w->conv_b[l - 1], 0, hc[l], 0, kEnc[l], (int)Rc, kEnc[l],
+                       kEnc[l - 1], 1, true));
+        in = hc[l];
+    }
+    hipLaunchKernelGGL(enc_l5_bwd_kernel, dim3(512), dim3(256), 0, stream, B, 512, 512, dg, w->conv_w[4], hc[4], gr->conv_w[4],
+                       dl[4]);
+    TRY(op.colsum(dg, 0, 512, B, 512, 1, gr->conv_b[4], 0));
+    for (int l = 4; l >= 1; --l) {
+        const float* below = l > 1 ? hc[l - 1] : xc;
+        TRY(op.lin_dw(dl[l], 0, kEnc[l], below, 0, kEnc[l - 1], gr->conv_w[l - 1], 0, (int)Rc, kEnc[l], kEnc[l - 1], 1));
+        TRY(op.colsum(dl[l], 0, kEnc[l], (int)Rc, kEnc[l], 1, gr->conv_b[l - 1], 0));
+        if (l > 1)
+            TRY(op.lin_dx(dl[l], 0, kEnc[l], w->conv_w[l - 1], 0, dl[l - 1], 0, kEnc[l - 1], (int)Rc, kEnc[l], kEnc[l - 1], 1,
+                          hc[l - 1], 0, kEnc[l - 1], nullptr, 0));
+    }
+    HP_RETURN_LAST_ERROR();
+}
+
+// =================================================================================================
+// Hypernetwork
+// =================================================================================================
+HP_API long hp_hypernet_saved_floats(int B) { return (long)B * (64 + 128 + 512 + 1024 + 2048); }
+HP_API long hp_hypernet_backward_workspace_floats(int B) { return (long)B * (64 + 128 + 512 + 1024 + 2048) + kSplitWs + 64; }
+
+// model/hyper_network.py:41-43.  t: saved trunk activations (hp_hypernet_saved_floats), theta (B, theta_ld)
+HP_API int hp_hypernet_forward(int B, int in_size, const float* latent, const HpHyperWeights* w, float* t, float* theta,
+                               int theta_ld, hipStream_t stream) {
+    HP_CHECK_ARG(B > 0 && in_size > 0 && latent && w && t && theta && w->n_heads > 0 && w->n_heads <= HP_MAX_HEADS);
+    Op op{stream, nullptr};
+    const float* in = latent;
+    int kin = in_size;
+    float* tl = t;
+    for (int l = 0; l < 5; ++l) {
+        TRY(op.lin_fwd(in, 0, kin, w->trunk_w[l], 0, w->trunk_b[l], 0, tl, 0, kTrunk[l], B, kTrunk[l], kin, 1, l < 4));
+        in = tl;
+        kin = kTrunk[l];
+        tl += (long)B * kTrunk[l];
+    }
+    int off = 0;
+    for (int hd = 0; hd < w->n_heads; ++hd) {
+        TRY(op.lin_fwd(in, 0, 2048, w->head_w[hd], 0, w->head_b[hd], 0, theta + off, 0, theta_ld, B, w->head_out[hd], 2048, 1,
+                       false));
+        off += w->head_out[hd];
+    }
+    HP_CHECK_ARG(off <= theta_ld);
+    HP_RETURN_LAST_ERROR();
+}
+
+HP_API int hp_hypernet_backward(int B, int in_size, const float* latent, const HpHyperWeights* w, const float* t,
+                                const float* grad_theta, int theta_ld, const HpHyperGrads* gr, float* grad_latent, float* ws,
+                                hipStream_t stream) {
+    HP_CHECK_ARG(B > 0 && in_size > 0 && latent && w && t && grad_theta && gr && ws);
+    const float* act[5];
+    {
+        const float* tl = t;
+        for (int l = 0; l < 5; ++l) {
+            act[l] = tl;
+            tl += (long)B * kTrunk[l];
+        }
+    }
+    float* p = ws;
+    float* dt[5];
+    for (int l = 0; l < 5; ++l) {
+        dt[l] = p;
+        p += (long)B * kTrunk[l];
+    }
+    Op op{stream, p};
+    // heads: dW_h = dtheta_h^T t5 ; db_h = colsum ; dt5 = sum_h dtheta_h W_h
+    int off = 0;
+    for (int hd = 0; hd < w->n_heads; ++hd) {
+        const int nh = w->head_out[hd];
+        TRY(op.lin_dw(grad_theta + off, 0, theta_ld, act[4], 0, 2048, gr->head_w[hd], 0, B, nh, 2048, 1));
+        TRY(op.colsum(grad_theta + off, 0, theta_ld, B, nh, 1, gr->head_b[hd], 0));
+        TRY(op.lin_dx(grad_theta + off, 0, theta_ld, w->head_w[hd], 0, dt[4], 0, 2048, B, nh, 2048, 1, nullptr, 0, 0,
+                      hd ? dt[4] : nullptr, 2048));
+        off += nh;
+    }
+    // trunk
+    for (int l = 4; l >= 0; --l) {
+        const float* below = l ? act[l - 1] : latent;
+        const int kin = l ? kTrunk[l - 1] : in_size;
+        TRY(op.lin_dw(dt[l], 0, kTrunk[l], below, 0, kin, gr->trunk_w[l], 0, B, kTrunk[l], kin, 1));
+        TRY(op.colsum(dt[l], 0, kTrunk[l], B, kTrunk[l], 1, gr->trunk_b[l], 0));
+        if (l > 0)
+            TRY(op.lin_dx(dt[l], 0, kTrunk[l], w->trunk_w[l], 0, dt[l - 1], 0, kin, B, kTrunk[l], kin, 1, act[l - 1], 0, kin,
+                          nullptr, 0));
+        else if (grad_latent)
+            TRY(op.lin_dx(dt[0], 0, kTrunk[0], w->trunk_w[0], 0, grad_latent, 0, kin, B, kTrunk[0], kin, 1, nullptr, 0, 0,
+                          nullptr, 0));
+    }
+    HP_RETURN_LAST_ERROR();
+}
+
+// =================================================================================================
+// Target network (batched over clouds)
+// =================================================================================================
+namespace {
+struct TnLayout {
+    int nl;            // number of linear layers (hidden + output)
+    int cin[HP_MAX_TN_LAYERS], cout[HP_MAX_TN_LAYERS];
+    long woff[HP_MAX_TN_LAYERS], boff[HP_MAX_TN_LAYERS];
+    long total, act_per_point;
+};
+bool tn_layout(int n_hidden, const int* channels, TnLayout* L) {
+    if (n_hidden < 1 || n_hidden + 1 > HP_MAX_TN_LAYERS) return false;
+    L->nl = n_hidden + 1;
+    long off = 0;
+    L->act_per_point = 0;
+    for (int l = 0; l < L->nl; ++l) {
+        L->cin[l] = l ? channels[l - 1] : 3;
+        L->cout[l] = l < n_hidden ? channels[l] : 3;
+        L->woff[l] = off;
+        off += (long)L->cin[l] * L->cout[l];
+        L->boff[l] = off;
+        off += L->cout[l];
+        if (l < n_hidden) L->act_per_point += channels[l];
+    }
+    L->total = off;
+    return true;
+}
+}  // namespace
+
+HP_API long hp_target_theta_size(int n_hidden, const int* channels) {
+    TnLayout L;
+    return tn_layout(n_hidden, channels, &L) ? L.total : -1;
+}
+HP_API long hp_target_saved_floats(int B, int N, int n_hidden, const int* channels) {
+    TnLayout L;
+    return tn_layout(n_hidden, channels, &L) ? (long)B * N * L.act_per_point : -1;
+}
+HP_API long hp_target_backward_workspace_floats(int B, int N, int n_hidden, const int* channels) {
+    TnLayout L;
+    return tn_layout(n_hidden, channels, &L) ? (long)B * N * L.act_per_point + kSplitWs + 64 : -1;
+}
+
+// model/target_network.py:31-38 for all B clouds at once.  theta (B, theta_ld): per-cloud weight
+// vector [W1 b1 | W2 b2 | ... | Wout bout], W row-major (out,in).  pts (B,N,3) -> y (B,N,3)
+// (the reference stores the transpose, rec[b] = y^T: the host returns y.permute(0,2,1)).
+// acts: post-ReLU activations of the hidden layers, kept for the backward.
+HP_API int hp_target_forward(int B, int N, int n_hidden, const int* channels, const float* theta, int theta_ld,
+                             const float* pts, float* acts, float* y, hipStream_t stream) {
+    TnLayout L;
+    HP_CHECK_ARG(B > 0 && N > 0 && theta && pts && acts && y && tn_layout(n_hidden, channels, &L) && L.total <= theta_ld);
+    Op op{stream, nullptr};
+    const float* in = pts;
+    float* a = acts;
+    for (int l = 0; l < L.nl; ++l) {
+        const bool last = (l == L.nl - 1);
+        float* out = last ? y : a;
+        TRY(op.lin_fwd(in, (long)N * L.cin[l], L.cin[l], theta + L.woff[l], theta_ld, theta + L.boff[l], theta_ld, out,
+                       (long)N * L.cout[l], L.cout[l], N, L.cout[l], L.cin[l], B, !last));
+        in = out;
+        if (!last) a += (long)B * N * L.cout[l];
+    }
+    HP_RETURN_LAST_ERROR();
+}
+
+// grad_y (B,N,3) -> grad_theta (B, theta_ld) (every one of the L.total entries is written)
+HP_API int hp_target_backward(int B, int N, int n_hidden, const int* channels, const float* theta, int theta_ld,
+                              const float* pts, const float* acts, const float* grad_y, float* grad_theta, float* ws,
+                              hipStream_t stream) {
+    TnLayout L;
+    HP_CHECK_ARG(B > 0 && N > 0 && theta && pts && acts && grad_y && grad_theta && ws && tn_layout(n_hidden, channels, &L) &&
+                 L.total <= theta_ld);
+    const float* act[HP_MAX_TN_LAYERS];
+    float* dl[HP_MAX_TN_LAYERS];
+    {
+        const float* a = acts;
+        float* p = ws;
+        for (int l = 0; l < n_hidden; ++l) {
+            act[l] = a;
+            dl[l] = p;
+            a += (long)B * N * L.cout[l];
+            p += (long)B * N * L.cout[l];
+        }
+        ws = p;
+    }
+    Op op{stream, ws};
+    const float* d = grad_y;   // gradient w.r.t. the pre-activation output of layer l
+    for (int l = L.nl - 1; l >= 0; --l) {
+        const float* below = l ? act[l - 1] : pts;
+        const int cin = L.cin[l], cout = L.cout[l];
+        TRY(op.lin_dw(d, (long)N * cout, cout, below, (long)N * cin, cin, grad_theta + L.woff[l], theta_ld, N, cout, cin, B));
+        TRY(op.colsum(d, (long)N * cout, cout, N, cout, B, grad_theta + L.boff[l], theta_ld));
+        if (l > 0) {
+            TRY(op.lin_dx(d, (long)N * cout, cout, theta + L.woff[l], theta_ld, dl[l - 1], (long)N * cin, cin, N, cout, cin, B,
+                          act[l - 1], (long)N * cin, cin, nullptr, 0));
+            d = dl[l - 1];
+        }
+    }
+    HP_RETURN_LAST_ERROR();
+}

@@ -1,0 +1,64 @@
+"""Drop-in for losses/champfer_loss.py:5-35 (the training loss).
+
+``ChamferLoss()(preds, gts)`` returns the batch SUM of squared nearest-neighbour distances in both
+directions as a 0-dim tensor with grad, like the reference, but through the fused HIP kernels
+(hp_chamfer_forward / hp_chamfer_backward): no (B,N,M) tensor is ever materialised.
+"""
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from .._lib import call, check_input, current_stream, load_library
+
+
+class _ChamferFunction(Function):
+    @staticmethod
+    def forward(ctx, preds, gts):
+        preds_c = preds.contiguous()   # the caller passes rec.permute(0,2,1) (core/epoch_loops.py:26)
+        gts_c = gts.contiguous()
+        check_input(preds_c, "preds")
+        check_input(gts_c, "gts")
+        b, n, m = preds_c.size(0), preds_c.size(1), gts_c.size(1)
+        if gts_c.size(0) != b or preds_c.size(2) != 3 or gts_c.size(2) != 3:
+            raise RuntimeError(f"ChamferLoss: incompatible shapes {tuple(preds.shape)} vs {tuple(gts.shape)}")
+        dev = preds_c.device
+        dist1 = torch.empty((b, n), dtype=torch.float32, device=dev)
+        idx1 = torch.empty((b, n), dtype=torch.int32, device=dev)
+        dist2 = torch.empty((b, m), dtype=torch.float32, device=dev)
+        idx2 = torch.empty((b, m), dtype=torch.int32, device=dev)
+        part = torch.empty((load_library().hp_chamfer_workspace_floats(b, n, m),), dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        call("hp_chamfer_forward", b, n, preds_c, m, gts_c, dist1, idx1, dist2, idx2, part, loss, current_stream(dev))
+        ctx.save_for_backward(preds_c, gts_c, idx1, idx2)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        preds_c, gts_c, idx1, idx2 = ctx.saved_tensors
+        b, n, m = preds_c.size(0), preds_c.size(1), gts_c.size(1)
+        g = grad_loss.to(torch.float32).contiguous()
+        grad_preds = torch.empty_like(preds_c)
+        grad_gts = torch.empty_like(gts_c)
+        call("hp_chamfer_backward", b, n, preds_c, m, gts_c, idx1, idx2, g, grad_preds, grad_gts,
+             current_stream(preds_c.device))
+        return grad_preds, grad_gts
+
+
+class ChamferLoss(nn.Module):
+
+    def __init__(self):
+        super(ChamferLoss, self).__init__()
+        self.use_cuda = torch.cuda.is_available()
+
+    def forward(self, preds, gts):
+        return _ChamferFunction.apply(preds, gts)
+
+    def batch_pairwise_dist(self, x, y):
+        """losses/champfer_loss.py:19-35 — kept for the evaluation callers (utils/metrics.py:78-83);
+        plain torch, not on the training path."""
+        xx = torch.bmm(x, x.transpose(2, 1))
+        yy = torch.bmm(y, y.transpose(2, 1))
+        zz = torch.bmm(x, y.transpose(2, 1))
+        rx = torch.diagonal(xx, dim1=1, dim2=2).unsqueeze(1).expand_as(zz.transpose(2, 1))
+        ry = torch.diagonal(yy, dim1=1, dim2=2).unsqueeze(1).expand_as(zz)
+        return rx.transpose(2, 1) + ry - 2 * zz

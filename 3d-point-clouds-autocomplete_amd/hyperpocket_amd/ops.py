@@ -1,0 +1,307 @@
+"""autograd bridges between PyTorch tensors and the model entry points of the C ABI.
+
+Each Function's forward/backward is ONE call into libhyperpocket_hip.so (which issues the whole
+launch sequence on the current stream); PyTorch only owns the memory and the autograd wiring.
+"""
+import ctypes
+from ctypes import c_int, c_long, c_void_p
+
+import torch
+from torch.autograd import Function
+
+from ._lib import HipExtensionError, call, check_input, current_stream, load_library, ptr
+
+HP_MAX_HEADS = 8
+
+
+class _EncoderPtrs(ctypes.Structure):  # HpEncoderWeights / HpEncoderGrads (csrc/hp_model.h)
+    _fields_ = [("conv_w", c_void_p * 5), ("conv_b", c_void_p * 5), ("fc_w", c_void_p), ("fc_b", c_void_p),
+                ("mu_w", c_void_p), ("mu_b", c_void_p), ("std_w", c_void_p), ("std_b", c_void_p)]
+
+
+class _HyperWeights(ctypes.Structure):  # HpHyperWeights
+    _fields_ = [("trunk_w", c_void_p * 5), ("trunk_b", c_void_p * 5), ("n_heads", c_int),
+                ("head_out", c_int * HP_MAX_HEADS), ("head_w", c_void_p * HP_MAX_HEADS),
+                ("head_b", c_void_p * HP_MAX_HEADS)]
+
+
+class _HyperGrads(ctypes.Structure):  # HpHyperGrads
+    _fields_ = [("trunk_w", c_void_p * 5), ("trunk_b", c_void_p * 5), ("head_w", c_void_p * HP_MAX_HEADS),
+                ("head_b", c_void_p * HP_MAX_HEADS)]
+
+
+def _dp(t):
+    return None if t is None else t.data_ptr()
+
+
+def _long_fn(name, *args):
+    fn = getattr(load_library(), name)
+    fn.restype = c_long
+    return fn(*args)
+
+
+# ---------------------------------------------------------------------------------------------
+# Gradient placement: a FlatParameters owner (parallel.py) may register, per parameter, a view of
+# its flat gradient buffer; backward then writes gradients straight into it (no copy before the
+# RCCL all-reduce / fused Adam).  Default: fresh tensors.
+# ---------------------------------------------------------------------------------------------
+_GRAD_VIEWS = {}
+
+
+def register_grad_view(param, view):
+    _GRAD_VIEWS[param.data_ptr()] = view
+
+
+def clear_grad_views():
+    _GRAD_VIEWS.clear()
+
+
+def _grad_buffer(param):
+    v = _GRAD_VIEWS.get(param.data_ptr())
+    if v is not None and v.shape == param.shape:
+        return v
+    return torch.empty_like(param, memory_format=torch.contiguous_format)
+
+
+def _encoder_struct(params, cls=_EncoderPtrs):
+    # params: conv_w x5, conv_b x5, fc_w, fc_b, mu_w, mu_b[, std_w, std_b]
+    s = cls()
+    for i in range(5):
+        s.conv_w[i] = _dp(params[i])
+        s.conv_b[i] = _dp(params[5 + i])
+    s.fc_w, s.fc_b, s.mu_w, s.mu_b = (_dp(p) for p in params[10:14])
+    if len(params) > 14:
+        s.std_w, s.std_b = _dp(params[14]), _dp(params[15])
+    return s
+
+
+class EncoderFunction(Function):
+    """model/encoder.py:43-53.  x: (B, Np, 3) contiguous.  params as listed in _encoder_struct.
+    Returns mu (plain) or (z, mu, exp(logvar)) (VAE)."""
+
+    @staticmethod
+    def forward(ctx, x, eps, out_size, *params):
+        check_input(x, "x")
+        is_vae = len(params) == 16
+        for i, p in enumerate(params):
+            check_input(p, f"encoder param {i}")
+        B, Np = x.size(0), x.size(1)
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        argidx = torch.empty((B, 512), dtype=torch.int32, device=dev)
+        g = torch.empty((B, 512), **f32)
+        f = torch.empty((B, 512), **f32)
+        mu = torch.empty((B, out_size), **f32)
+        lv = z = explv = None
+        if is_vae:
+            check_input(eps, "eps")
+            lv, z, explv = (torch.empty((B, out_size), **f32) for _ in range(3))
+        ws = torch.empty((_long_fn("hp_encoder_forward_workspace_floats", B, Np),), **f32)
+        w = _encoder_struct(params)
+        call("hp_encoder_forward", B, Np, x, ctypes.byref(w), out_size, int(is_vae), eps, argidx, g, f, mu, lv, z, explv,
+             ws, current_stream(dev))
+        ctx.is_vae, ctx.out_size = is_vae, out_size
+        ctx.save_for_backward(x, eps, argidx, g, f, lv, *params)
+        if is_vae:
+            return z, mu, explv
+        return mu
+
+    @staticmethod
+    def backward(ctx, *grads):
+        x, eps, argidx, g, f, lv, *params = ctx.saved_tensors
+        B, Np = x.size(0), x.size(1)
+        dev = x.device
+        if ctx.is_vae:
+            gz, gmu, gexplv = (None if t is None else t.contiguous() for t in grads)
+            gout = gz
+        else:
+            gout, gmu, gexplv = grads[0].contiguous(), None, None
+        out = [_grad_buffer(p) for p in params]
+        ws = torch.empty((_long_fn("hp_encoder_backward_workspace_floats", B, ctx.out_size),), dtype=torch.float32,
+                         device=dev)
+        w, gr = _encoder_struct(params), _encoder_struct(out)
+        call("hp_encoder_backward", B, Np, x, ctypes.byref(w), ctx.out_size, int(ctx.is_vae), eps, argidx, g, f, lv,
+             gout, gmu, gexplv, ctypes.byref(gr), ws, current_stream(dev))
+        return (None, None, None, *out)
+
+
+class HyperNetFunction(Function):
+    """model/hyper_network.py:41-43.  params: trunk_w x5, trunk_b x5, head_w x H, head_b x H."""
+
+    @staticmethod
+    def forward(ctx, latent, n_heads, *params):
+        latent = latent.contiguous()
+        check_input(latent, "latent")
+        B, in_size = latent.shape
+        dev = latent.device
+        w = _HyperWeights()
+        for i in range(5):
+            w.trunk_w[i], w.trunk_b[i] = _dp(params[i]), _dp(params[5 + i])
+        w.n_heads = n_heads
+        total = 0
+        for h in range(n_heads):
+            hw, hb = params[10 + h], params[10 + n_heads + h]
+            w.head_w[h], w.head_b[h], w.head_out[h] = _dp(hw), _dp(hb), hw.size(0)
+            total += hw.size(0)
+        t = torch.empty((_long_fn("hp_hypernet_saved_floats", B),), dtype=torch.float32, device=dev)
+        theta = torch.empty((B, total), dtype=torch.float32, device=dev)
+        call("hp_hypernet_forward", B, in_size, latent, ctypes.byref(w), t, theta, total, current_stream(dev))
+        ctx.n_heads = n_heads
+        ctx.save_for_backward(latent, t, *params)
+        return theta
+
+    @staticmethod
+    def backward(ctx, grad_theta):
+        latent, t, *params = ctx.saved_tensors
+        n_heads = ctx.n_heads
+        grad_theta = grad_theta.contiguous()
+        B, in_size = latent.shape
+        dev = latent.device
+        w, gr = _HyperWeights(), _HyperGrads()
+        out = [_grad_buffer(p) for p in params]
+        for i in range(5):
+            w.trunk_w[i], w.trunk_b[i] = _dp(params[i]), _dp(params[5 + i])
+            gr.trunk_w[i], gr.trunk_b[i] = _dp(out[i]), _dp(out[5 + i])
+        w.n_heads = n_heads
+        for h in range(n_heads):
+            w.head_w[h], w.head_b[h], w.head_out[h] = _dp(params[10 + h]), _dp(params[10 + n_heads + h]), params[10 + h].size(0)
+            gr.head_w[h], gr.head_b[h] = _dp(out[10 + h]), _dp(out[10 + n_heads + h])
+        grad_latent = torch.empty_like(latent) if ctx.needs_input_grad[0] else None
+        ws = torch.empty((_long_fn("hp_hypernet_backward_workspace_floats", B),), dtype=torch.float32, device=dev)
+        call("hp_hypernet_backward", B, in_size, latent, ctypes.byref(w), t, grad_theta, grad_theta.size(1), ctypes.byref(gr),
+             grad_latent, ws, current_stream(dev))
+        return (grad_latent, None, *out)
+
+
+class TargetNetworkFunction(Function):
+    """All B per-cloud target networks at once (model/full_model.py:70-74 + model/target_network.py).
+    theta (B, T), points (B, N, 3) -> y (B, N, 3)."""
+
+    @staticmethod
+    def forward(ctx, theta, points, channels):
+        theta = theta.contiguous()
+        points = points.contiguous()
+        check_input(theta, "theta")
+        check_input(points, "points")
+        B, N = points.size(0), points.size(1)
+        dev = theta.device
+        ch = (c_int * len(channels))(*channels)
+        need = _long_fn("hp_target_theta_size", len(channels), ch)
+        if need != theta.size(1) or theta.size(0) != B:
+            # model/target_network.py:29 `assert split_index == len(weights)`
+            raise HipExtensionError(f"target network expects {need} weights per cloud, got {tuple(theta.shape)}")
+        acts = torch.empty((_long_fn("hp_target_saved_floats", B, N, len(channels), ch),), dtype=torch.float32, device=dev)
+        y = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+        call("hp_target_forward", B, N, len(channels), ch, theta, theta.size(1), points, acts, y, current_stream(dev))
+        ctx.channels = tuple(channels)
+        ctx.save_for_backward(theta, points, acts)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        theta, points, acts = ctx.saved_tensors
+        grad_y = grad_y.contiguous()
+        B, N = points.size(0), points.size(1)
+        dev = theta.device
+        ch = (c_int * len(ctx.channels))(*ctx.channels)
+        grad_theta = torch.empty_like(theta)
+        ws = torch.empty((_long_fn("hp_target_backward_workspace_floats", B, N, len(ctx.channels), ch),), dtype=torch.float32,
+                         device=dev)
+        call("hp_target_backward", B, N, len(ctx.channels), ch, theta, theta.size(1), points,
+             acts, grad_y, grad_theta, ws, current_stream(dev))
+        return grad_theta, None, None
+
+
+class KLDFunction(Function):
+    """core/epoch_loops.py:29-30: 0.5*sum(exp(v)+mu^2-1-v)/B with v = the encoder's exp(logvar)."""
+
+    @staticmethod
+    def forward(ctx, explv, mu, batch):
+        explv, mu = explv.contiguous(), mu.contiguous()
+        check_input(explv, "explv")
+        check_input(mu, "mu")
+        out = torch.empty((), dtype=torch.float32, device=mu.device)
+        call("hp_kld_forward", c_long(mu.numel()), batch, explv, mu, out, current_stream(mu.device))
+        ctx.batch = batch
+        ctx.save_for_backward(explv, mu)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        explv, mu = ctx.saved_tensors
+        gv, gm = torch.empty_like(explv), torch.empty_like(mu)
+        call("hp_kld_backward", c_long(mu.numel()), ctx.batch, explv, mu, g.contiguous(), gv, gm, current_stream(mu.device))
+        return gv, gm, None
+
+
+def kld_loss(explv, mu, batch=None):
+    return KLDFunction.apply(explv, mu, mu.size(0) if batch is None else batch)
+
+
+def sample_points(B, N, coef, seed, offset, device):
+    """Decoder input points for B clouds (utils/points.py distribution) drawn on the device."""
+    out = torch.empty((B, N, 3), dtype=torch.float32, device=device)
+    call("hp_sample_points", c_long(B * N), float(coef), ctypes.c_ulonglong(seed & (2 ** 64 - 1)),
+         ctypes.c_ulonglong(offset & (2 ** 64 - 1)), out, current_stream(device))
+    return out
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    """In-place fused Adam over flat fp32 tensors (torch.optim.Adam semantics, wd=0, amsgrad=False)."""
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        check_input(t, n)
+    call("hp_adam_step", c_long(p.numel()), p, g, m, v, float(lr), float(beta1), float(beta2), float(eps), int(step),
+         float(grad_scale), current_stream(p.device))
+
+
+def gemm(A, B, bias=None, relu=False, trans_a=False, trans_b=True, mask=None, add=None, ksplit=1):
+    """Thin test hook over hp_gemm_f32 for 2-D / 3-D (batched) fp32 tensors:
+    C = epi(op(A) @ op(B)); trans_b=True means B is stored (N, K) like an nn.Linear weight."""
+    class _Desc(ctypes.Structure):
+        _fields_ = [("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("bias", c_void_p), ("mask", c_void_p),
+                    ("add", c_void_p), ("ws", c_void_p),
+                    ("sAz", c_long), ("sBz", c_long), ("sCz", c_long), ("sBiasz", c_long), ("sMaskz", c_long), ("sAddz", c_long),
+                    ("sAi", c_long), ("sAk", c_long), ("sBk", c_long), ("sBj", c_long),
+                    ("ldc", c_int), ("ldmask", c_int), ("ldadd", c_int),
+                    ("M", c_int), ("N", c_int), ("K", c_int), ("batch", c_int), ("ksplit", c_int), ("flags", c_int)]
+    batched = A.dim() == 3
+    A3 = A if batched else A.unsqueeze(0)
+    B3 = B if B.dim() == 3 else B.unsqueeze(0)
+    for t, n in ((A3, "A"), (B3, "B")):
+        check_input(t, n)
+    batch = A3.size(0)
+    M, K = (A3.size(2), A3.size(1)) if trans_a else (A3.size(1), A3.size(2))
+    N = B3.size(1) if trans_b else B3.size(2)
+    C = torch.empty((batch, M, N), dtype=torch.float32, device=A.device)
+    d = _Desc()
+    d.A, d.B, d.C = A3.data_ptr(), B3.data_ptr(), C.data_ptr()
+    d.sAz = A3.stride(0)
+    d.sBz = B3.stride(0) if B3.size(0) > 1 else 0
+    d.sCz = M * N
+    d.sAi, d.sAk = (1, A3.size(2)) if trans_a else (A3.size(2), 1)
+    d.sBk, d.sBj = (1, B3.size(2)) if trans_b else (B3.size(2), 1)
+    d.ldc, d.M, d.N, d.K, d.batch, d.ksplit = N, M, N, K, batch, ksplit
+    flags = 0
+    if bias is not None:
+        check_input(bias, "bias")
+        d.bias, d.sBiasz = bias.data_ptr(), (bias.stride(0) if bias.dim() == 2 else 0)
+        flags |= 1
+    if relu:
+        flags |= 2
+    if mask is not None:
+        mask3 = mask if mask.dim() == 3 else mask.unsqueeze(0)
+        check_input(mask3, "mask")
+        d.mask, d.sMaskz, d.ldmask = mask3.data_ptr(), M * N, N
+        flags |= 4
+    if add is not None:
+        add3 = add if add.dim() == 3 else add.unsqueeze(0)
+        check_input(add3, "add")
+        d.add, d.sAddz, d.ldadd = add3.data_ptr(), M * N, N
+        flags |= 8
+    d.flags = flags
+    ws = None
+    if ksplit > 1:
+        ws = torch.empty((batch * ksplit * M * N,), dtype=torch.float32, device=A.device)
+        d.ws = ws.data_ptr()
+    call("hp_gemm_f32", ctypes.byref(d), current_stream(A.device))
+    return C if batched else C[0]

@@ -22,8 +22,13 @@
  *     contraction produces for  x*x+y*y+z*z  (nndistance.cu:31): fma(z,z,fma(y,y,x*x)).
  *     The HIP kernels use the same chain, so distances and arg-min indices are
  *     comparable bit for bit.
- *   - __expf (approxmatch.cu:86,131,185) is restated with expf(); the HIP kernels use
- *     the hardware exp2 path, so EMD parity is a tolerance, not bit equality.
+ *   - __expf(x) (approxmatch.cu:86,131,185) is CUDA's fast exponential, defined as
+ *     exp2(x * log2(e)) evaluated in fp32 (ex2.approx of the rounded product).  It is
+ *     restated as exp2f(x * 1.4426950408889634f): the rounding of the product is part
+ *     of the reference's arithmetic and the auction amplifies it (replacing it by a
+ *     correctly rounded expf moves single match entries by up to 1.5e-3 and the cost by
+ *     3e-5 relative, measured here).  The HIP kernels evaluate the same product and use
+ *     the hardware v_exp_f32 (1 ulp), so EMD parity is a tolerance, not bit equality.
  *   - per-thread sequential float accumulations keep the reference's order
  *     (ascending l / k); block tree reductions (approxmatch.cu:244-252,279-296) are
  *     restated as double accumulations.
@@ -101,6 +106,8 @@ int ref_nndistancegrad(int b, int n, const float *xyz1, int m, const float *xyz2
     return 0;
 }
 
+static inline float fast_expf(float x) { return exp2f(x * 1.4426950408889634f); }
+
 static inline float pair_d2(const float *p, const float *q) {
     /* (x2-x1)*(x2-x1)+(y2-y1)*(y2-y1)+(z2-z1)*(z2-z1)  (approxmatch.cu:85) with the
      * same left-to-right fma contraction as above */
@@ -131,7 +138,7 @@ int ref_approxmatch(int b, int n, int m, const float *xyz1, const float *xyz2,
             for (int k = 0; k < n; k++) {
                 float suml = 1e-9f;
                 for (int l = 0; l < m; l++) {
-                    float w = expf(level * pair_d2(P + k * 3, Q + l * 3)) * remainR[l];
+                    float w = fast_expf(level * pair_d2(P + k * 3, Q + l * 3)) * remainR[l];
                     suml += w;
                 }
                 ratioL[k] = remainL[k] / suml;
@@ -140,7 +147,7 @@ int ref_approxmatch(int b, int n, int m, const float *xyz1, const float *xyz2,
             for (int l = 0; l < m; l++) {
                 float sumr = 0;
                 for (int k = 0; k < n; k++) {
-                    float w = expf(level * pair_d2(P + k * 3, Q + l * 3)) * ratioL[k];
+                    float w = fast_expf(level * pair_d2(P + k * 3, Q + l * 3)) * ratioL[k];
                     sumr += w;
                 }
                 sumr *= remainR[l];
@@ -153,7 +160,7 @@ int ref_approxmatch(int b, int n, int m, const float *xyz1, const float *xyz2,
                 float suml = 0;
                 float rl = ratioL[k];
                 for (int l = 0; l < m; l++) {
-                    float w = expf(level * pair_d2(P + k * 3, Q + l * 3)) * rl * ratioR[l];
+                    float w = fast_expf(level * pair_d2(P + k * 3, Q + l * 3)) * rl * ratioR[l];
                     M[(size_t)l * n + k] += w;
                     suml += w;
                 }
