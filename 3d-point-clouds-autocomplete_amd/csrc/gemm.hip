@@ -219,27 +219,55 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams p) {
     }
 }
 
-// out[z][j] = sum_i X[z](i,j)  (bias gradients).  One workgroup per 64 columns x row-slab, ordered.
+// Column sums (bias gradients): out[z][j] = sum_i X[z](i,j).
+// Stage 1: a workgroup owns 64 columns x one row slab; its 4 waves stride the slab's rows (each wave reads
+// 256 contiguous bytes per row) and combine through LDS -> partial[z][slab][j].  Stage 2 adds the slabs in slab
+// order.  Ordered and atomic-free.  With one slab stage 1 writes `out` directly.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long sXz, int ldx, int M, int N,
                                                      const float* __restrict__ mask, long sMaskz, int ldmask,
-                                                     float* __restrict__ out, long sOz) {
+                                                     float* __restrict__ out, long sOz, int slabs, int rows_per_slab) {
     __shared__ float red[4][64];
-    const int z = blockIdx.y;
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int w = threadIdx.x >> 6;
+    const int z = blockIdx.z, slab = blockIdx.y;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     const float* x = X + (long)z * sXz;
     const float* mk = mask ? mask + (long)z * sMaskz : nullptr;
-    float s = 0.f;
+    const int r0 = slab * rows_per_slab, r1 = min(M, r0 + rows_per_slab);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < N) {
-        for (int i = w; i < M; i += 4) {
+        int i = r0 + w;
+        if (!mk) {
+            for (; i + 12 < r1; i += 16) {
+                s0 += x[(long)i * ldx + c];
+                s1 += x[(long)(i + 4) * ldx + c];
+                s2 += x[(long)(i + 8) * ldx + c];
+                s3 += x[(long)(i + 12) * ldx + c];
+            }
+        }
+        for (; i < r1; i += 4) {
             float v = x[(long)i * ldx + c];
             if (mk) v = (mk[(long)i * ldmask + c] > 0.f) ? v : 0.f;
-            s += v;
+            s0 += v;
         }
     }
-    red[w][threadIdx.x & 63] = s;
+    red[w][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (w == 0 && c < N) out[(long)z * sOz + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (w == 0 && c < N) {
+        const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (slabs == 1) out[(long)z * sOz + c] = t;
+        else out[((long)z * slabs + slab) * N + c] = t;   // out = partial workspace
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, int slabs, int N,
+                                                            float* __restrict__ out, long sOz) {
+    const int z = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    const float* p = partial + (long)z * slabs * N + c;
+    float s = 0.f;
+    for (int k = 0; k < slabs; ++k) s += p[(long)k * N];
+    out[(long)z * sOz + c] = s;
 }
 
 template <int BM, int BN, int WGM, int WGN>
@@ -303,13 +331,28 @@ HP_API int hp_gemm_f32(const HpGemmDesc* d, hipStream_t stream) {
     HP_RETURN_LAST_ERROR();
 }
 
-// Column sums (bias gradients): out[z][j] = sum_i (mask(i,j)>0 ? X(i,j) : 0)
+// Column sums (bias gradients): out[z][j] = sum_i (mask(i,j)>0 ? X(i,j) : 0).  `ws` (may be NULL) holds
+// hp_colsum_workspace_floats floats; without it the rows are not split across workgroups.
+HP_API long hp_colsum_workspace_floats(int batch, int M, int N) {
+    (void)M;
+    return (long)batch * 128 * N;
+}
+
 HP_API int hp_colsum_f32(int batch, int M, int N, const float* X, long sXz, int ldx, const float* mask, long sMaskz,
-                         int ldmask, float* out, long sOz, hipStream_t stream) {
+                         int ldmask, float* out, long sOz, float* ws, hipStream_t stream) {
     HP_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0);
     if (batch == 0 || N == 0) return 0;
     HP_CHECK_ARG(batch <= 65535);
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, batch), dim3(256), 0, stream, X, sXz, ldx, M, N, mask, sMaskz, ldmask,
-                       out, sOz);
+    const int colblocks = (N + 63) / 64;
+    int slabs = 1;
+    if (ws && M >= 512) {
+        const long base = (long)colblocks * batch;
+        slabs = (int)std::min<long>(128, std::max<long>(1, std::min<long>((1024 + base - 1) / base, M / 128)));
+    }
+    const int rows_per_slab = (M + slabs - 1) / slabs;
+    hipLaunchKernelGGL(colsum_kernel, dim3(colblocks, slabs, batch), dim3(256), 0, stream, X, sXz, ldx, M, N, mask, sMaskz,
+                       ldmask, slabs == 1 ? out : ws, sOz, slabs, rows_per_slab);
+    if (slabs > 1)
+        hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 255) / 256, batch), dim3(256), 0, stream, ws, slabs, N, out, sOz);
     HP_RETURN_LAST_ERROR();
 }

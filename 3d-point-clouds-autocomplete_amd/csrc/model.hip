@@ -23,7 +23,7 @@
 
 extern "C" int hp_gemm_f32(const HpGemmDesc* d, hipStream_t stream);
 extern "C" int hp_colsum_f32(int batch, int M, int N, const float* X, long sXz, int ldx, const float* mask, long sMaskz,
-                             int ldmask, float* out, long sOz, hipStream_t stream);
+                             int ldmask, float* out, long sOz, float* ws, hipStream_t stream);
 
 namespace {
 
@@ -92,7 +92,9 @@ struct Op {
         return hp_gemm_f32(&d, s);
     }
     int colsum(const float* X, long sXz, int ldx, int M, int N, int batch, float* out, long sOz) const {
-        return hp_colsum_f32(batch, M, N, X, sXz, ldx, nullptr, 0, 0, out, sOz, s);
+        // the split-K slab area doubles as the row-slab workspace (stream order keeps the uses apart)
+        const bool fits = (long)batch * 128 * N <= kSplitWs;
+        return hp_colsum_f32(batch, M, N, X, sXz, ldx, nullptr, 0, 0, out, sOz, fits ? splitws : nullptr, s);
     }
 };
 

@@ -91,6 +91,7 @@ class FullModel(nn.Module):
             gt_shape[1], gt_shape[2] = gt_shape[2], gt_shape[1]
 
         latent, mu, logvar = self.mode.get_latent(self, existing, missing, noise, eps)
+        self._last_latent = latent   # TrainEngine hooks its gradient: "hypernetwork backward has been enqueued"
 
         target_networks_weights = self.hyper_network(latent)
         batch, n_points = target_networks_weights.size(0), gt_shape[2]

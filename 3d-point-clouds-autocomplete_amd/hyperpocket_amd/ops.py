@@ -59,7 +59,9 @@ def clear_grad_views():
 def _grad_buffer(param):
     v = _GRAD_VIEWS.get(param.data_ptr())
     if v is not None and v.shape == param.shape:
-        return v
+        # a FRESH view object: autograd's AccumulateGrad keeps (instead of cloning) a gradient nobody else references,
+        # so param.grad ends up aliasing the flat buffer with no copy
+        return v.view(v.shape)
     return torch.empty_like(param, memory_format=torch.contiguous_format)
 
 

@@ -67,6 +67,135 @@ int hp_chamfer_backward(int b, int n, const float* preds, int m, const float* gt
                         const float* grad_loss /* device scalar */, float* grad_preds, float* grad_gts,
                         hpStream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * fp32 matrix-core GEMM family (v_mfma_f32_32x32x2_f32) — the dense contractions PyTorch/cuBLAS
+ * perform for the reference's nn.Conv1d(k=1)/nn.Linear/torch.mm calls (model/encoder.py:14-36,
+ * model/hyper_network.py:16-43, model/target_network.py:31-38) and their autograd backward.
+ *   C[z](i,j) = epi( sum_k A[z](i,k) B[z](k,j) );  epi = (+bias[j]) (+add(i,j)) (ReLU) (*(mask(i,j)>0))
+ * ------------------------------------------------------------------------------------------ */
+#define HP_GEMM_BIAS 1
+#define HP_GEMM_RELU 2
+#define HP_GEMM_MASK 4
+#define HP_GEMM_ADD 8
+
+typedef struct HpGemmDesc {
+    const float* A;    /* A(i,k) at A + z*sAz + i*sAi + k*sAk (one of sAi,sAk is 1) */
+    const float* B;    /* B(k,j) at B + z*sBz + k*sBk + j*sBj (one of sBk,sBj is 1) */
+    float* C;          /* C(i,j) at C + z*sCz + i*ldc + j                           */
+    const float* bias; /* bias(j) at bias + z*sBiasz + j                            */
+    const float* mask; /* mask(i,j) at mask + z*sMaskz + i*ldmask + j               */
+    const float* add;  /* add(i,j) at add + z*sAddz + i*ldadd + j                   */
+    float* ws;         /* split-K slabs: hp_gemm_workspace_floats(desc) floats       */
+    long sAz, sBz, sCz, sBiasz, sMaskz, sAddz;
+    long sAi, sAk, sBk, sBj;
+    int ldc, ldmask, ldadd;
+    int M, N, K, batch;
+    int ksplit; /* <=1: no split; >1: ordered (atomic-free) split-K through `ws` */
+    int flags;
+} HpGemmDesc;
+
+long hp_gemm_workspace_floats(const HpGemmDesc* d);
+int hp_gemm_f32(const HpGemmDesc* d /* host struct */, hpStream_t stream);
+/* out[z][j] = sum_i (mask ? (mask(i,j)>0 ? X(i,j) : 0) : X(i,j))  — bias gradients */
+long hp_colsum_workspace_floats(int batch, int M, int N);
+int hp_colsum_f32(int batch, int M, int N, const float* X, long sXz, int ldx, const float* mask, long sMaskz,
+                  int ldmask, float* out, long sOz, float* ws /* or NULL */, hpStream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Model entry points.  Parameter tables hold device pointers to tensors laid out exactly as the
+ * reference's nn.Module parameters (row-major (out,in); Conv1d weights (out,in,1)).
+ * ------------------------------------------------------------------------------------------ */
+#define HP_MAX_HEADS 8
+#define HP_MAX_TN_LAYERS 8
+
+typedef struct HpEncoderWeights { /* model/encoder.py:14-36: conv 3-64-128-256-512-512, fc 512, mu/std (out,512) */
+    const float* conv_w[5];
+    const float* conv_b[5];
+    const float* fc_w;
+    const float* fc_b;
+    const float* mu_w;
+    const float* mu_b;
+    const float* std_w; /* NULL for a non-VAE encoder */
+    const float* std_b;
+} HpEncoderWeights;
+
+typedef struct HpEncoderGrads {
+    float* conv_w[5];
+    float* conv_b[5];
+    float* fc_w;
+    float* fc_b;
+    float* mu_w;
+    float* mu_b;
+    float* std_w;
+    float* std_b;
+} HpEncoderGrads;
+
+typedef struct HpHyperWeights { /* model/hyper_network.py:16-36 */
+    const float* trunk_w[5];
+    const float* trunk_b[5];
+    int n_heads;
+    int head_out[HP_MAX_HEADS];
+    const float* head_w[HP_MAX_HEADS];
+    const float* head_b[HP_MAX_HEADS];
+} HpHyperWeights;
+
+typedef struct HpHyperGrads {
+    float* trunk_w[5];
+    float* trunk_b[5];
+    float* head_w[HP_MAX_HEADS];
+    float* head_b[HP_MAX_HEADS];
+} HpHyperGrads;
+
+/* Encoder.forward (model/encoder.py:43-53).  x (B,Np,3) contiguous.  Outputs: argidx/g (B,512) the max-pool
+ * arg-max / value, f (B,512) the fc activation, mu (B,out); VAE also lv (raw std_layer output), z = eps*exp(lv)+mu,
+ * explv = exp(lv) (what the reference returns as "logvar").  ws: hp_encoder_forward_workspace_floats. */
+long hp_encoder_forward_workspace_floats(int B, int Np);
+int hp_encoder_forward(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size, int is_vae,
+                       const float* eps, int* argidx, float* g, float* f, float* mu, float* lv, float* z, float* explv,
+                       float* ws, hpStream_t stream);
+/* Gradients of every encoder parameter (autograd of the above).  grad_out = d/dz (VAE) or d/dmu (plain);
+ * grad_mu / grad_explv = direct gradients on the VAE outputs (may be NULL). */
+long hp_encoder_backward_workspace_floats(int B, int out_size);
+int hp_encoder_backward(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size, int is_vae,
+                        const float* eps, const int* argidx, const float* g, const float* f, const float* lv,
+                        const float* grad_out, const float* grad_mu, const float* grad_explv, const HpEncoderGrads* grads,
+                        float* ws, hpStream_t stream);
+
+/* HyperNetwork.forward (model/hyper_network.py:41-43): latent (B,in) -> theta (B,theta_ld); t = saved trunk
+ * activations (hp_hypernet_saved_floats floats) for the backward. */
+long hp_hypernet_saved_floats(int B);
+int hp_hypernet_forward(int B, int in_size, const float* latent, const HpHyperWeights* w, float* t, float* theta,
+                        int theta_ld, hpStream_t stream);
+long hp_hypernet_backward_workspace_floats(int B);
+int hp_hypernet_backward(int B, int in_size, const float* latent, const HpHyperWeights* w, const float* t,
+                         const float* grad_theta, int theta_ld, const HpHyperGrads* grads, float* grad_latent /* or NULL */,
+                         float* ws, hpStream_t stream);
+
+/* The B per-cloud TargetNetworks of one step at once (model/full_model.py:70-74, model/target_network.py:6-45).
+ * theta (B,theta_ld): [W1 b1 | W2 b2 | ... | Wout bout] per cloud; pts (B,N,3) -> y (B,N,3) (rec[b] = y[b]^T).
+ * acts: hidden activations kept for the backward (hp_target_saved_floats floats). */
+long hp_target_theta_size(int n_hidden, const int* channels);
+long hp_target_saved_floats(int B, int N, int n_hidden, const int* channels);
+int hp_target_forward(int B, int N, int n_hidden, const int* channels, const float* theta, int theta_ld, const float* pts,
+                      float* acts, float* y, hpStream_t stream);
+long hp_target_backward_workspace_floats(int B, int N, int n_hidden, const int* channels);
+int hp_target_backward(int B, int N, int n_hidden, const int* channels, const float* theta, int theta_ld, const float* pts,
+                       const float* acts, const float* grad_y, float* grad_theta, float* ws, hpStream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Auxiliary kernels of the step
+ * ------------------------------------------------------------------------------------------ */
+/* Decoder input points (utils/points.py:8-36 distribution) for total = B*N points, Philox(seed, offset). */
+int hp_sample_points(long total, float coef, unsigned long long seed, unsigned long long offset, float* out,
+                     hpStream_t stream);
+/* KLD term of core/epoch_loops.py:29-30 and its gradients */
+int hp_kld_forward(long n, int batch, const float* explv, const float* mu, float* out, hpStream_t stream);
+int hp_kld_backward(long n, int batch, const float* explv, const float* mu, const float* grad_out, float* grad_explv,
+                    float* grad_mu, hpStream_t stream);
+/* torch.optim.Adam(lr, betas, eps, weight_decay=0, amsgrad=False) over n contiguous fp32 parameters (core/main.py:62-66) */
+int hp_adam_step(long n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2, float eps,
+                 int step, float grad_scale, hpStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

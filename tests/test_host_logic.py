@@ -1,0 +1,170 @@
+"""CPU suite: host-side logic that needs no GPU — module structure / state_dict compatibility with the
+reference, the reference-exact point sampler, the flat parameter layout and the 2-rank (gloo)
+gradient exchange with the sharded-loss semantics of SURVEY §8e."""
+import copy
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import golden
+
+
+def model_config(random_out=128, real_out=128):
+    return {
+        "random_encoder": {"output_size": random_out, "use_bias": True, "relu_slope": 0.2},
+        "real_encoder": {"output_size": real_out, "use_bias": True, "relu_slope": 0.2},
+        "hyper_network": {"use_bias": True, "relu_slope": 0.2},
+        "target_network": {"use_bias": True, "relu_slope": 0.2, "freeze_layers_learning": False,
+                           "layer_out_channels": [32, 64, 128, 64]},
+        "target_network_input": {"constant": False,
+                                 "normalization": {"enable": True, "type": "progressive", "epoch": 100}},
+    }
+
+
+@pytest.mark.parametrize("name", ["model_small", "model_hyperrec", "model_hypercloud"])
+def test_state_dict_matches_reference_names_shapes_and_seeded_values(name, ref):
+    from hyperpocket_amd.core.setup import weights_init
+    from hyperpocket_amd.model.full_model import FullModel
+    g = golden(name)
+    torch.manual_seed(int(g["seed"]))
+    m = FullModel(copy.deepcopy(model_config(int(g["random_out"]), int(g["real_out"]))))
+    m.apply(weights_init)
+    sd = m.state_dict()
+    keys = [k[3:].replace("__", ".") for k in g if k.startswith("w__")]
+    assert sorted(sd.keys()) == sorted(keys)            # reference checkpoints load unchanged
+    for k, v in sd.items():
+        s = g["w__" + k.replace(".", "__")]
+        assert abs(v.double().sum().item() - s[0]) <= 1e-9 * max(1.0, abs(s[0])) + 1e-9, k
+        assert abs(v.double().norm().item() - s[1]) <= 1e-9 * s[1] + 1e-12, k
+    # mode-filtered parameters() (model/full_model.py:82-83) and the helper API
+    n = sum(p.numel() for p in m.parameters())
+    assert n == {"model_small": 43328515, "model_hyperrec": 42490499}.get(name, n)
+    assert m.mode.has_generativity() == (name == "model_small")
+    assert m.get_noise_size() == int(g["random_out"])
+
+
+def test_mode_resolution_errors():
+    from hyperpocket_amd.model.full_model import FullModel
+    with pytest.raises(ValueError):
+        FullModel(copy.deepcopy(model_config(0, 0)))
+
+
+def test_reference_point_sampler_bit_exact():
+    from hyperpocket_amd.utils.points import generate_points, normalization_coef
+    g = golden("points")
+    cfg = {"target_network_input": model_config()["target_network_input"]}
+    for seed, epoch in [(5, 1), (6, 37), (7, 100), (8, 250)]:
+        torch.manual_seed(seed)
+        assert np.array_equal(generate_points(cfg, epoch, (2048, 3)).numpy(), g[f"seed{seed}_epoch{epoch}"])
+    torch.manual_seed(9)
+    assert np.array_equal(generate_points(cfg, 1, (512, 3), normalize_points=False).numpy(), g["seed9_nonorm"])
+    assert normalization_coef(cfg, 1) == 0.0 and normalization_coef(cfg, 100) == 1.0 and normalization_coef(cfg, 500) == 1.0
+
+
+def test_flat_parameters_layout():
+    from hyperpocket_amd.model.full_model import FullModel
+    from hyperpocket_amd.parallel import FlatParameters
+    from hyperpocket_amd import ops
+    torch.manual_seed(0)
+    m = FullModel(copy.deepcopy(model_config()))
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    flat = FlatParameters(m)
+    assert flat.is_intact()
+    assert flat.total >= 43328515 and flat.total - 43328515 < 4 * len(flat.params)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k])                 # values preserved, now views of one buffer
+    # bucket order = the order backward produces gradients: heads, trunk, encoders
+    assert flat.names[0].startswith("hyper_network.output") and flat.names[-1].startswith("real_encoder")
+    (lo0, hi0), (lo1, hi1), (lo2, hi2) = flat.buckets
+    assert lo0 == 0 and hi0 == lo1 and hi1 == lo2 and hi2 == flat.total
+    assert hi0 >= 38953539                               # the heads: 90 % of the bytes
+    # the registered gradient views alias the flat gradient buffer
+    p = dict(m.named_parameters())["hyper_network.output.2.weight"]
+    gv = ops._grad_buffer(p)
+    gv.fill_(3.0)
+    assert flat.grad_of("hyper_network.output.2.weight").eq(3.0).all() and flat.grad.sum().item() == 3.0 * p.numel()
+    ops.clear_grad_views()
+
+
+# --------------------------------------------------------------------------------------------- 2-rank gloo
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _dp_worker(rank, world, port, out):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "3d-point-clouds-autocomplete_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from oracle import hyperpocket_ref as ref
+    from hyperpocket_amd.parallel import FlatParameters, GradientReducer
+    from hyperpocket_amd.model.full_model import FullModel
+    from hyperpocket_amd.core.setup import weights_init
+    from hyperpocket_amd import ops
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    torch.manual_seed(11)
+    model = FullModel(copy.deepcopy(model_config()))
+    model.apply(weights_init)
+    flat = FlatParameters(model)
+    reducer = GradientReducer(flat)
+    # global batch of 4 clouds, 2 per rank; the oracle stands in for the HIP kernels (test only)
+    g = torch.Generator().manual_seed(5)
+    ex, mi = torch.rand(4, 40, 3, generator=g) - 0.5, torch.rand(4, 40, 3, generator=g) - 0.5
+    pts, eps = torch.rand(4, 80, 3, generator=g) * 2 - 1, torch.randn(4, 128, generator=g)
+    gt = torch.cat([ex, mi], 1)
+    sl = slice(rank * 2, rank * 2 + 2)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    rec, explv, mu, _ = ref.full_forward(P, ex[sl], mi[sl], pts[sl], eps[sl])
+    loss = 0.05 * ref.chamfer_loss(gt[sl], rec.permute(0, 2, 1)) \
+        + 0.5 * (torch.exp(explv) + torch.square(mu) - 1 - explv).sum() / (2 * world)   # KLD / GLOBAL batch
+    loss.backward()
+    with torch.no_grad():
+        for name in flat.names:
+            gr = P[name].grad
+            if gr is not None:
+                flat.grad_of(name).copy_(gr)
+    reducer.launch(0)          # heads first (overlap order), the rest in finish()
+    reducer.finish()
+    if rank == 0:
+        # single-process reference: the whole batch at once, reference loss (KLD / B)
+        Pg = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+        loss_all, _, _, _ = ref.step_loss(Pg, ex, mi, gt, pts, eps)
+        loss_all.backward()
+        worst = 0.0
+        for name in flat.names:
+            want = Pg[name].grad
+            if want is None:
+                assert float(flat.grad_of(name).abs().max()) == 0.0
+                continue
+            err = (flat.grad_of(name) - want).abs().max().item() / max(want.abs().max().item(), 1e-30)
+            worst = max(worst, err)
+        out.put(worst)
+    ops.clear_grad_views()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_exchange_equals_global_batch_gradient():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    worst = out.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert worst < 2e-3, worst     # fp32 summation-order noise (incl. arg-max near-ties) only
