@@ -312,16 +312,19 @@ HP_API int hp_gemm_f32(const HpGemmDesc* d, hipStream_t stream) {
     p.vecA = (d->sAk == 1) && (d->sAi % 4 == 0) && (d->sAz % 4 == 0) && aligned16(d->A);
     p.vecB = (d->sBk == 1) && (d->sBj % 4 == 0) && (d->sBz % 4 == 0) && aligned16(d->B);
 
+    // Tile choice: the largest tile that still yields >= ~2 workgroups per CU; skinny problems (M <= 64, the
+    // hypernetwork's B x 19011 heads) and small ones fall through to smaller tiles instead of idling CUs.
     int rc;
-    const long tilesA = (long)((d->M + 127) / 128) * ((d->N + 127) / 128) * d->batch * p.ksplit;
+    const long zs = (long)d->batch * p.ksplit;
+    auto wgs = [&](int bm, int bn) { return (long)((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn) * zs; };
     if (d->N <= 32)
         rc = launch_cfg<128, 32, 4, 1>(p, d->batch, stream);
-    else if (d->M <= 64 && d->N > 64)
-        rc = launch_cfg<64, 128, 2, 2>(p, d->batch, stream);
-    else if (d->M <= 64 || d->N <= 64 || tilesA < 192)
-        rc = launch_cfg<64, 64, 2, 2>(p, d->batch, stream);
-    else
+    else if (d->M > 64 && d->N > 64 && wgs(128, 128) >= 384)
         rc = launch_cfg<128, 128, 2, 2>(p, d->batch, stream);
+    else if (d->N > 64 && wgs(64, 128) >= 512)
+        rc = launch_cfg<64, 128, 2, 2>(p, d->batch, stream);
+    else
+        rc = launch_cfg<64, 64, 2, 2>(p, d->batch, stream);
     if (rc) return rc;
     if (p.ksplit > 1) {
         const long mn = (long)d->M * d->N;

@@ -62,6 +62,10 @@ struct Op {
         d.bias = b; d.sBiasz = sbz;
         d.M = M; d.N = N; d.K = K; d.batch = batch;
         d.flags = (b ? HP_GEMM_BIAS : 0) | (relu ? HP_GEMM_RELU : 0);
+        if (splitws) {
+            d.ksplit = pick_ksplit(M, N, K, batch);
+            d.ws = splitws;
+        }
         return hp_gemm_f32(&d, s);
     }
     // dX(MxK, ldx) = [add +] dY(MxN, ldy) W(NxK), optionally * (mask > 0)
@@ -310,14 +314,15 @@ HP_API int hp_encoder_backward(int B, int Np, const float* x, const HpEncoderWei
 // =================================================================================================
 // Hypernetwork
 // =================================================================================================
-HP_API long hp_hypernet_saved_floats(int B) { return (long)B * (64 + 128 + 512 + 1024 + 2048); }
+// saved trunk activations + the split-K slab area the skinny (M = B) forward GEMMs use
+HP_API long hp_hypernet_saved_floats(int B) { return (long)B * (64 + 128 + 512 + 1024 + 2048) + kSplitWs + 64; }
 HP_API long hp_hypernet_backward_workspace_floats(int B) { return (long)B * (64 + 128 + 512 + 1024 + 2048) + kSplitWs + 64; }
 
 // model/hyper_network.py:41-43.  t: saved trunk activations (hp_hypernet_saved_floats), theta (B, theta_ld)
 HP_API int hp_hypernet_forward(int B, int in_size, const float* latent, const HpHyperWeights* w, float* t, float* theta,
                                int theta_ld, hipStream_t stream) {
     HP_CHECK_ARG(B > 0 && in_size > 0 && latent && w && t && theta && w->n_heads > 0 && w->n_heads <= HP_MAX_HEADS);
-    Op op{stream, nullptr};
+    Op op{stream, t + ((long)B * (64 + 128 + 512 + 1024 + 2048) + 3) / 4 * 4};
     const float* in = latent;
     int kin = in_size;
     float* tl = t;
