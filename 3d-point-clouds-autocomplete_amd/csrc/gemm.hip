@@ -19,7 +19,7 @@
 //   Split-K (ksplit > 1): partial slabs in `ws`, combined in split order by a second kernel that
 //   applies the epilogue — ordered and atomic-free, so results are run-to-run identical.
 //
-// Workgroup = 4 waves; a wave owns TMxTN tiles of 32x32 (f32x16 accumulators); BK = 16.
+// Workgroup = 4 waves; a wave owns TMxTN tiles of 32x32 (f32x16 accumulators).
 // Tile ids are remapped so that the 8 XCDs each get a contiguous run of tiles (neighbouring
 // tiles share an A or B panel in that XCD's L2).
 #include "hp_common.h"
@@ -29,8 +29,10 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16;
-constexpr int LDK = 20;  // padded LDS row (floats): 80 B keeps 16-B alignment, b128 reads conflict-free
+// BK (k-tile depth) is a template parameter: 32 for the big 128x128 tile (half the barriers per MFMA, full
+// 128-byte lines per staged row), 16 for the small tiles.  LDS rows are padded by 4 floats (BK+4): 16-byte
+// aligned and conflict-free for the ds_read_b128 fragment reads at both depths.
+constexpr int kMaxBK = 32;
 
 struct KParams {
     const float* A;
@@ -65,11 +67,24 @@ __device__ __forceinline__ float4 ld4(const float* __restrict__ base, long rowof
     return v;
 }
 
-template <int BM, int BN, int WGM, int WGN>
+// branch-free staging load of 4 consecutive k for one (clamped) row: a 16-byte load when the operand is K-contiguous,
+// 4 lane-coalesced strided loads when it is i/j-contiguous
+template <bool KC>
+__device__ __forceinline__ float4 ld4_fast(const float* __restrict__ p, long s_k) {
+    if (KC) return *reinterpret_cast<const float4*>(p);
+    return make_float4(p[0], p[s_k], p[2 * s_k], p[3 * s_k]);
+}
+
+// MODE < 0: generic loaders (bounds checks, any alignment, K tails).  MODE >= 0: fast loaders — bit0: A is
+// K-contiguous, bit1: B is K-contiguous; rows/cols are clamped instead of predicated (the epilogue never stores
+// them), the k-range is a multiple of BK and K-contiguous operands are 16-byte aligned (checked on the host).
+// The generic loaders' divergent-branch scaffolding costs ~30 % of the MFMA rate (tools/exp_gemm.py).
+template <int BM, int BN, int WGM, int WGN, int BK, int MODE>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const KParams p) {
     constexpr int NT = WGM * WGN * 64;
+    constexpr int LDK = BK + 4, KQ = BK / 4;   // KQ float4 groups per staged row
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
-    constexpr int NA = (BM * 4 + NT - 1) / NT, NB = (BN * 4 + NT - 1) / NT;
+    constexpr int NA = (BM * KQ + NT - 1) / NT, NB = (BN * KQ + NT - 1) / NT;
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
     __shared__ __attribute__((aligned(16))) float As[BM * LDK];
     __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
@@ -91,21 +106,22 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const KParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WGN, wn = wid % WGN;
     const int r = lane & 31, h = lane >> 5;
-    const bool a_kc = (p.sAk == 1), b_kc = (p.sBk == 1);
+    const bool a_kc = MODE >= 0 ? (MODE & 1) != 0 : (p.sAk == 1);
+    const bool b_kc = MODE >= 0 ? (MODE & 2) != 0 : (p.sBk == 1);
 
     // staging assignment: each thread moves NA (NB) groups of 4 consecutive k of one row
     int a_row[NA], a_kq[NA], b_row[NB], b_kq[NB];
 #pragma unroll
     for (int e = 0; e < NA; ++e) {
         const int idx = tid + e * NT;
-        a_row[e] = a_kc ? (idx >> 2) : (idx % BM);
-        a_kq[e] = a_kc ? (idx & 3) : (idx / BM);
+        a_row[e] = a_kc ? (idx / KQ) : (idx % BM);
+        a_kq[e] = a_kc ? (idx % KQ) : (idx / BM);
     }
 #pragma unroll
     for (int e = 0; e < NB; ++e) {
         const int idx = tid + e * NT;
-        b_row[e] = b_kc ? (idx >> 2) : (idx % BN);
-        b_kq[e] = b_kc ? (idx & 3) : (idx / BN);
+        b_row[e] = b_kc ? (idx / KQ) : (idx % BN);
+        b_kq[e] = b_kc ? (idx % KQ) : (idx / BN);
     }
 
     f32x16 acc[TM][TN];
@@ -117,17 +133,43 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const KParams p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     float4 ra[NA], rb[NB];
+    // fast path: per-thread base pointers (row clamped into range), advanced by BK*s_k per k-tile
+    const float* pa[NA];
+    const float* pb[NB];
+    if (MODE >= 0) {
+#pragma unroll
+        for (int e = 0; e < NA; ++e)
+            pa[e] = A + (long)min(row0 + a_row[e], p.M - 1) * p.sAi + (long)(kbeg + a_kq[e] * 4) * p.sAk;
+#pragma unroll
+        for (int e = 0; e < NB; ++e)
+            pb[e] = B + (long)min(col0 + b_row[e], p.N - 1) * p.sBj + (long)(kbeg + b_kq[e] * 4) * p.sBk;
+    }
     auto fetch = [&](int k0) {
+        if (MODE >= 0) {
+#pragma unroll
+            for (int e = 0; e < NA; ++e)
+                if (BM * KQ % NT == 0 || tid + e * NT < BM * KQ) {
+                    ra[e] = ld4_fast<(MODE & 1) != 0>(pa[e], p.sAk);
+                    pa[e] += (long)BK * p.sAk;
+                }
+#pragma unroll
+            for (int e = 0; e < NB; ++e)
+                if (BN * KQ % NT == 0 || tid + e * NT < BN * KQ) {
+                    rb[e] = ld4_fast<(MODE & 2) != 0>(pb[e], p.sBk);
+                    pb[e] += (long)BK * p.sBk;
+                }
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < NA; ++e) {
             const int row = row0 + a_row[e];
-            const bool ok = (tid + e * NT < BM * 4) && row < p.M;
+            const bool ok = (tid + e * NT < BM * KQ) && row < p.M;
             ra[e] = ld4(A, (long)row * p.sAi, k0 + a_kq[e] * 4, p.sAk, ok, kend, p.vecA);
         }
 #pragma unroll
         for (int e = 0; e < NB; ++e) {
             const int col = col0 + b_row[e];
-            const bool ok = (tid + e * NT < BN * 4) && col < p.N;
+            const bool ok = (tid + e * NT < BN * KQ) && col < p.N;
             rb[e] = ld4(B, (long)col * p.sBj, k0 + b_kq[e] * 4, p.sBk, ok, kend, p.vecB);
         }
     };
@@ -136,14 +178,14 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const KParams p) {
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
 #pragma unroll
         for (int e = 0; e < NA; ++e)
-            if (tid + e * NT < BM * 4) *reinterpret_cast<float4*>(&As[a_row[e] * LDK + a_kq[e] * 4]) = ra[e];
+            if (BM * KQ % NT == 0 || tid + e * NT < BM * KQ) *reinterpret_cast<float4*>(&As[a_row[e] * LDK + a_kq[e] * 4]) = ra[e];
 #pragma unroll
         for (int e = 0; e < NB; ++e)
-            if (tid + e * NT < BN * 4) *reinterpret_cast<float4*>(&Bs[b_row[e] * LDK + b_kq[e] * 4]) = rb[e];
+            if (BN * KQ % NT == 0 || tid + e * NT < BN * KQ) *reinterpret_cast<float4*>(&Bs[b_row[e] * LDK + b_kq[e] * 4]) = rb[e];
         __syncthreads();
         if (k0 + BK < kend) fetch(k0 + BK);  // next tile's global loads fly under this tile's MFMAs
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < BK / 8; ++t) {
             float4 a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -270,12 +312,20 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
     out[(long)z * sOz + c] = s;
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int BK>
 int launch_cfg(KParams& p, int batch, hipStream_t stream) {
+    p.kchunk = (p.kchunk + BK - 1) / BK * BK;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
-    dim3 grid(p.tiles_m * p.tiles_n, batch * p.ksplit);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN>), grid, dim3(WGM * WGN * 64), 0, stream, p);
+    dim3 grid(p.tiles_m * p.tiles_n, batch * p.ksplit), block(WGM * WGN * 64);
+    const bool a_kc = p.sAk == 1, b_kc = p.sBk == 1;
+    // every split's k-range must be whole k-tiles, K-contiguous operands need 16-byte loads
+    const bool fast = p.K % BK == 0 && (!a_kc || p.vecA) && (!b_kc || p.vecB) && p.K > 0;
+    if (!fast) hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, -1>), grid, block, 0, stream, p);
+    else if (a_kc && b_kc) hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, 3>), grid, block, 0, stream, p);
+    else if (a_kc) hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, 1>), grid, block, 0, stream, p);
+    else if (b_kc) hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, 2>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, 0>), grid, block, 0, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -305,8 +355,8 @@ HP_API int hp_gemm_f32(const HpGemmDesc* d, hipStream_t stream) {
     p.sAi = d->sAi; p.sAk = d->sAk; p.sBk = d->sBk; p.sBj = d->sBj;
     p.ldc = d->ldc; p.ldmask = d->ldmask; p.M = d->M; p.N = d->N; p.K = d->K; p.flags = d->flags;
     p.ksplit = d->ksplit > 1 ? d->ksplit : 1;
-    p.kchunk = ((d->K + p.ksplit - 1) / p.ksplit + BK - 1) / BK * BK;
-    if (p.kchunk == 0) p.kchunk = BK;
+    p.kchunk = ((d->K + p.ksplit - 1) / p.ksplit + kMaxBK - 1) / kMaxBK * kMaxBK;   // multiple of every BK in use
+    if (p.kchunk == 0) p.kchunk = kMaxBK;
     // a split whose range is empty still writes its (zero) slab, so every slab is initialised
     HP_CHECK_ARG(p.ksplit == 1 || d->ws);
     p.vecA = (d->sAk == 1) && (d->sAi % 4 == 0) && (d->sAz % 4 == 0) && aligned16(d->A);
@@ -318,13 +368,13 @@ HP_API int hp_gemm_f32(const HpGemmDesc* d, hipStream_t stream) {
     const long zs = (long)d->batch * p.ksplit;
     auto wgs = [&](int bm, int bn) { return (long)((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn) * zs; };
     if (d->N <= 32)
-        rc = launch_cfg<128, 32, 4, 1>(p, d->batch, stream);
+        rc = launch_cfg<128, 32, 4, 1, 16>(p, d->batch, stream);
     else if (d->M > 64 && d->N > 64 && wgs(128, 128) >= 384)
-        rc = launch_cfg<128, 128, 2, 2>(p, d->batch, stream);
+                rc = launch_cfg<128, 128, 2, 2, 16>(p, d->batch, stream);
     else if (d->N > 64 && wgs(64, 128) >= 512)
-        rc = launch_cfg<64, 128, 2, 2>(p, d->batch, stream);
+        rc = launch_cfg<64, 128, 2, 2, 16>(p, d->batch, stream);
     else
-        rc = launch_cfg<64, 64, 2, 2>(p, d->batch, stream);
+        rc = launch_cfg<64, 64, 2, 2, 16>(p, d->batch, stream);
     if (rc) return rc;
     if (p.ksplit > 1) {
         const long mn = (long)d->M * d->N;

@@ -11,12 +11,8 @@
 //    cloud (R points per lane in registers) and sweeps the other set through a 16 KB LDS tile of
 //    float4 candidates read as wave-uniform ds_read_b128 broadcasts.  No global round trip of the
 //    running minimum (the reference keeps it in global memory between tiles, nndistance.cu:122).
-//  * approxmatch: the reference walks 32 persistent blocks over the batch and read-modify-writes the
-//    (m x n) match matrix nine times (302 MB per 2048^2 cloud).  Here each of the 27 dependent
-//    phases is a chip-wide launch over (cloud, row tile); the per-level scaling vectors ratioL/ratioR
-//    are kept (9*(n+m) floats per cloud) and `match` is produced by ONE final pass that re-evaluates
-//    the nine exponentials per pair and accumulates them in level order (same summation order as the
-//    reference's nine += passes) — 16.8 MB written once per cloud instead of 302 MB moved.
+//  * the approximate matching itself (approxmatch.cu:34-213) is in emd.hip; here: the two kernels that
+//    consume a materialised `match` (MatchCost / MatchCostGrad API parity).
 //  * all reductions are ordered (no float atomics) except the scatter half of nndistancegrad, which
 //    is a scatter by construction (the reference uses atomicAdd there too, nndistance.cu:146-151).
 #include "hp_common.h"
@@ -176,152 +172,10 @@ __global__ __launch_bounds__(kThreads) void nn_grad_scatter_kernel(int b, int n,
 }
 
 // ------------------------------------------------------------------------------------------------
-// Approximate EMD matching (auction with 9 annealing levels, approxmatch.cu:55-211)
+// Match-based cost / gradients (API parity with MatchCost / MatchCostGrad; the matching itself and the
+// match-free fused path live in emd.hip)
 // ------------------------------------------------------------------------------------------------
-constexpr int kLevels = 9;
-constexpr float kLog2e = 1.4426950408889634f;
-
-__host__ __device__ inline float level_of(int lev) {  // lev 0..8  <->  j = 7..-1, level = -4^j
-    // exact powers of four
-    const float t[kLevels] = {-16384.f, -4096.f, -1024.f, -256.f, -64.f, -16.f, -4.f, -1.f, -0.25f};
-    return t[lev];
-}
-
-__global__ __launch_bounds__(kThreads) void approx_init_kernel(int n, int m, float* __restrict__ temp, float multiL, float multiR) {
-    float* remL = temp + (size_t)blockIdx.y * (n + m) * 2;
-    float* remR = remL + n;
-    for (int j = blockIdx.x * kThreads + threadIdx.x; j < n + m; j += gridDim.x * kThreads) {
-        if (j < n) remL[j] = multiL;
-        else remR[j - n] = multiR;
-    }
-}
-
-// One phase of one level.  PASS 1: ratioL  (approxmatch.cu:60-93)   rows = set1, candidates = set2 weighted remainR
-//                           PASS 2: ratioR / remainR update (:109-142) rows = set2, candidates = set1 weighted ratioL
-//                           PASS 3: remainL update (:161-194)          rows = set1, candidates = set2 weighted ratioR
-// temp per cloud: [remainL n | remainR m | ratioL n | ratioR m] (the reference's layout, :35);
-// ws per cloud:   [level][ratioL n | ratioR m]   (kept for the single final match pass).
-template <int PASS, int R>
-__global__ __launch_bounds__(kThreads) void approx_pass_kernel(int n, int m, const float* __restrict__ xyz1,
-                                                               const float* __restrict__ xyz2, float* __restrict__ temp,
-                                                               float* __restrict__ ws, int lev, float level_l2e) {
-    __shared__ float4 tile[kTile];
-    const int cloud = blockIdx.y, tid = threadIdx.x;
-    float* remL = temp + (size_t)cloud * (n + m) * 2;
-    float* remR = remL + n;
-    float* ratioL = remL + n + m;
-    float* ratioR = ratioL + n;
-    float* wsL = ws + ((size_t)cloud * kLevels + lev) * (n + m);
-    float* wsR = wsL + n;
-
-    const int nr = (PASS == 2) ? m : n;
-    const int nc = (PASS == 2) ? n : m;
-    const float* rows = (PASS == 2 ? xyz2 + (size_t)cloud * m * 3 : xyz1 + (size_t)cloud * n * 3);
-    const float* cand = (PASS == 2 ? xyz1 + (size_t)cloud * n * 3 : xyz2 + (size_t)cloud * m * 3);
-    const float* cw = (PASS == 1) ? remR : (PASS == 2 ? ratioL : ratioR);
-
-    float px[R], py[R], pz[R], rowf[R], acc[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int k = blockIdx.x * (kThreads * R) + r * kThreads + tid;
-        px[r] = py[r] = pz[r] = 0.f;
-        rowf[r] = 1.0f;
-        if (k < nr) {
-            px[r] = rows[k * 3 + 0];
-            py[r] = rows[k * 3 + 1];
-            pz[r] = rows[k * 3 + 2];
-            if (PASS == 3) rowf[r] = ratioL[k];
-        }
-        acc[r] = (PASS == 1) ? 1e-9f : 0.f;
-    }
-    for (int l0 = 0; l0 < nc; l0 += kTile) {
-        const int cnt = min(kTile, nc - l0);
-        for (int t = tid; t < cnt; t += kThreads) {
-            const float* s = cand + (size_t)(l0 + t) * 3;
-            tile[t] = make_float4(s[0], s[1], s[2], cw[l0 + t]);
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int l = 0; l < cnt; ++l) {
-            const float4 c = tile[l];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const float d = hp::sqdist(c.x - px[r], c.y - py[r], c.z - pz[r]);
-                const float e = __builtin_amdgcn_exp2f(level_l2e * d);
-                acc[r] += (e * rowf[r]) * c.w;   // rowf == 1 exactly for passes 1 and 2
-            }
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int k = blockIdx.x * (kThreads * R) + r * kThreads + tid;
-        if (k >= nr) continue;
-        if (PASS == 1) {
-            const float v = remL[k] / acc[r];
-            ratioL[k] = v;
-            wsL[k] = v;
-        } else if (PASS == 2) {
-            const float rr = remR[k];
-            const float sumr = acc[r] * rr;
-            const float consumption = fminf(rr / (sumr + 1e-9f), 1.0f);
-            const float v = consumption * rr;
-            ratioR[k] = v;
-            wsR[k] = v;
-            remR[k] = fmaxf(0.0f, rr - sumr);
-        } else {
-            remL[k] = fmaxf(0.0f, remL[k] - acc[r]);
-        }
-    }
-}
-
-// match[l*n+k] = sum over levels (in level order) of exp(level*d_kl) * ratioL_lev[k] * ratioR_lev[l]
-constexpr int kLT = 64;  // l rows per workgroup
-__global__ __launch_bounds__(kThreads) void approx_match_kernel(int n, int m, const float* __restrict__ xyz1,
-                                                                const float* __restrict__ xyz2, const float* __restrict__ ws,
-                                                                float* __restrict__ match) {
-    __shared__ float4 q[kLT];
-    __shared__ float rR[kLevels][kLT];
-    const int cloud = blockIdx.z, tid = threadIdx.x;
-    const int k = blockIdx.x * kThreads + tid;
-    const int l0 = blockIdx.y * kLT;
-    const int cnt = min(kLT, m - l0);
-    const float* wsc = ws + (size_t)cloud * kLevels * (n + m);
-    for (int t = tid; t < cnt; t += kThreads) {
-        const float* s = xyz2 + ((size_t)cloud * m + l0 + t) * 3;
-        q[t] = make_float4(s[0], s[1], s[2], 0.f);
-    }
-    for (int t = tid; t < kLevels * kLT; t += kThreads) {
-        const int lev = t / kLT, l = t % kLT;
-        rR[lev][l] = (l < cnt) ? wsc[(size_t)lev * (n + m) + n + l0 + l] : 0.f;
-    }
-    float px = 0, py = 0, pz = 0, rL[kLevels];
-#pragma unroll
-    for (int lev = 0; lev < kLevels; ++lev) rL[lev] = 0.f;
-    if (k < n) {
-        const float* s = xyz1 + ((size_t)cloud * n + k) * 3;
-        px = s[0];
-        py = s[1];
-        pz = s[2];
-#pragma unroll
-        for (int lev = 0; lev < kLevels; ++lev) rL[lev] = wsc[(size_t)lev * (n + m) + k];
-    }
-    __syncthreads();
-    if (k >= n) return;
-    float* out = match + ((size_t)cloud * m + l0) * n + k;
-    for (int l = 0; l < cnt; ++l) {
-        const float4 c = q[l];
-        const float d = hp::sqdist(c.x - px, c.y - py, c.z - pz);
-        float acc = 0.f;
-#pragma unroll
-        for (int lev = 0; lev < kLevels; ++lev) {
-            const float e = __builtin_amdgcn_exp2f((level_of(lev) * kLog2e) * d);
-            acc += (e * rL[lev]) * rR[lev][l];
-        }
-        out[(size_t)l * n] = acc;
-    }
-}
-
+constexpr int kLT = 64;  // match rows per workgroup
 // cost partials: one per workgroup tile, combined in fixed order by matchcost_finish_kernel
 __global__ __launch_bounds__(kThreads) void matchcost_kernel(int n, int m, const float* __restrict__ xyz1,
                                                              const float* __restrict__ xyz2, const float* __restrict__ match,
@@ -454,17 +308,6 @@ int launch_nn(int b, int n, const float* xyz, int m, const float* xyz2, float* r
     return (int)hipGetLastError();
 }
 
-template <int R>
-void launch_approx_levels(int b, int n, int m, const float* xyz1, const float* xyz2, float* temp, float* ws, hipStream_t stream) {
-    const int nbL = (n + kThreads * R - 1) / (kThreads * R), nbR = (m + kThreads * R - 1) / (kThreads * R);
-    for (int lev = 0; lev < kLevels; ++lev) {
-        const float l2 = level_of(lev) * kLog2e;
-        hipLaunchKernelGGL((approx_pass_kernel<1, R>), dim3(nbL, b), dim3(kThreads), 0, stream, n, m, xyz1, xyz2, temp, ws, lev, l2);
-        hipLaunchKernelGGL((approx_pass_kernel<2, R>), dim3(nbR, b), dim3(kThreads), 0, stream, n, m, xyz1, xyz2, temp, ws, lev, l2);
-        hipLaunchKernelGGL((approx_pass_kernel<3, R>), dim3(nbL, b), dim3(kThreads), 0, stream, n, m, xyz1, xyz2, temp, ws, lev, l2);
-    }
-}
-
 }  // namespace
 
 // ================================================================================================
@@ -524,36 +367,6 @@ HP_API int hp_chamfer_backward(int b, int n, const float* preds, int m, const fl
                        grad_loss, 0, idx2, grad_preds, grad_gts);
     hipLaunchKernelGGL(nn_grad_scatter_kernel, dim3(blocks), dim3(kThreads), 0, stream, b, n, preds, m, gts, grad_loss, 0, idx1,
                        grad_loss, 0, idx2, grad_preds, grad_gts);
-    HP_RETURN_LAST_ERROR();
-}
-
-// floats of scratch hp_approxmatch needs besides `temp`
-HP_API long hp_approxmatch_workspace_floats(int b, int n, int m) { return (long)b * kLevels * ((long)n + m); }
-
-// replaces approxmatch(...)  structural_loss.cpp:11 / approxmatch.cu:330-338.
-// match (b,m,n) and temp (b,2(n+m)) as in the reference; `ws` is extra scratch (see header).
-HP_API int hp_approxmatch(int b, int n, int m, const float* xyz1, const float* xyz2, float* match, float* temp, float* ws,
-                          hipStream_t stream) {
-    HP_CHECK_ARG(b >= 0 && n > 0 && m > 0);
-    if (b == 0) return 0;
-    float multiL, multiR;
-    if (n >= m) {
-        multiL = 1;
-        multiR = (float)(n / m);  // integer division (approxmatch.cu:37-43)
-    } else {
-        multiL = (float)(m / n);
-        multiR = 1;
-    }
-    hipLaunchKernelGGL(approx_init_kernel, dim3((n + m + kThreads - 1) / kThreads, b), dim3(kThreads), 0, stream, n, m, temp,
-                       multiL, multiR);
-    // One lane alone on a SIMD issues a VALU op every 4 cycles, two waves reach the 2-cycle rate
-    // (MI355X_MICROARCH.md cycle constants): keep >= 2 waves per SIMD (>= 512 workgroups) before
-    // spending registers on 2 rows per lane.
-    const long wg2 = (long)b * ((std::max(n, m) + kThreads * 2 - 1) / (kThreads * 2));
-    if (wg2 >= 1024) launch_approx_levels<2>(b, n, m, xyz1, xyz2, temp, ws, stream);
-    else launch_approx_levels<1>(b, n, m, xyz1, xyz2, temp, ws, stream);
-    hipLaunchKernelGGL(approx_match_kernel, dim3((n + kThreads - 1) / kThreads, (m + kLT - 1) / kLT, b), dim3(kThreads), 0, stream,
-                       n, m, xyz1, xyz2, ws, match);
     HP_RETURN_LAST_ERROR();
 }
 

@@ -40,11 +40,21 @@ int hp_nndistancegrad(int b, int n, const float* xyz1, int m, const float* xyz2,
 
 /* approxmatch  (structural_loss.cpp:11, approxmatch.cu:330-338)
  * match (b, m, n), temp (b, 2*(n+m)) as in the reference.  One extra argument: `ws`, scratch of
- * hp_approxmatch_workspace_floats(b,n,m) floats (the per-level scaling vectors; lets `match` be
- * written once instead of read-modify-written nine times). */
+ * hp_approxmatch_workspace_floats(b,n,m) floats (packed candidate records incl. the per-level scaling
+ * vectors; lets `match` be written once instead of read-modify-written nine times). */
 long hp_approxmatch_workspace_floats(int b, int n, int m);
 int hp_approxmatch(int b, int n, int m, const float* xyz1, const float* xyz2, float* match, float* temp, float* ws,
                    hpStream_t stream);
+
+/* Match-free EMD (what match_cost.py:9-46 computes through ApproxMatch + MatchCost + MatchCostGrad, without ever
+ * writing the (b,m,n) match tensor): cost (b,) and grad1 = d cost/d xyz1 in one sweep; hp_emd_backward gives
+ * grad2 = d cost/d xyz2 from the packed records hp_emd_forward left in `ws` (hp_approxmatch_workspace_floats).
+ * partials: hp_emd_partials_floats floats.  temp as in hp_approxmatch. */
+long hp_emd_partials_floats(int b, int n);
+int hp_emd_forward(int b, int n, int m, const float* xyz1, const float* xyz2, float* temp, float* ws, float* partials,
+                   float* cost, float* grad1 /* or NULL */, hpStream_t stream);
+int hp_emd_backward(int b, int n, int m, const float* xyz1, const float* xyz2, const float* ws, float* grad2,
+                    hpStream_t stream);
 
 /* matchcost  (structural_loss.cpp:12, approxmatch.cu:340-347); `partials`: scratch of
  * hp_matchcost_workspace_floats floats (ordered two-stage sum instead of one block per cloud). */

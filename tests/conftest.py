@@ -6,11 +6,14 @@ package (3d-point-clouds-autocomplete_amd/).
 """
 import ctypes
 import os
+import os
 import subprocess
 import sys
 
 import numpy as np
 import pytest
+
+os.environ.setdefault("OMP_NUM_THREADS", "16")   # the C oracle parallelises over clouds; a 256-core GPU host oversubscribes badly
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG_DIR = os.path.join(ROOT, "3d-point-clouds-autocomplete_amd")

@@ -183,6 +183,27 @@ def test_match_cost_autograd_function(oracle_lib):
     np.testing.assert_allclose(C.grad.cpu().numpy(), o2 * wn, atol=5e-5, rtol=1e-3)
 
 
+def test_fused_match_cost_equals_materialised_path(backend):
+    """match_cost (match-free: hp_emd_forward/backward) against ApproxMatch -> MatchCost -> MatchCostGrad on the GPU:
+    same match entries evaluated in the same order -> cost and grad1 agree to fp32 rounding of the final sums."""
+    from hyperpocket_amd.utils.pytorch_structural_losses.match_cost import match_cost
+    for b, n, m in [(3, 257, 257), (2, 500, 250), (2, 100, 300)]:
+        a, c = _clouds(31 + n, b, n, m)
+        A, C = _dev(a).requires_grad_(True), _dev(c).requires_grad_(True)
+        cost = match_cost(A, C)
+        cost.sum().backward()
+        match, _ = backend.ApproxMatch(_dev(a), _dev(c))
+        cost2 = backend.MatchCost(_dev(a), _dev(c), match)
+        g1, g2 = backend.MatchCostGrad(_dev(a), _dev(c), match)
+        np.testing.assert_allclose(cost.detach().cpu().numpy(), cost2.cpu().numpy(), rtol=2e-6)
+        np.testing.assert_allclose(A.grad.cpu().numpy(), g1.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(C.grad.cpu().numpy(), g2.cpu().numpy(), rtol=1e-4, atol=2e-6)
+    # only the second argument needs a gradient in training (match_cost(gt, rec))
+    A, C = _dev(a), _dev(c).requires_grad_(True)
+    match_cost(A, C).sum().backward()
+    assert C.grad is not None
+
+
 def test_emd_full_size_properties(backend):
     # B=32, N=2048 (BASELINE config 2): mass conservation, identical clouds, permutation equivariance
     g = torch.Generator(device="cuda").manual_seed(1)
