@@ -17,8 +17,12 @@
 //     summation order as the reference's nine `match +=` passes) — or never: the fused cost/gradient
 //     kernels consume the records directly (match-free EMD), so the (b,m,n) tensor and
 //     its 19 GB of read-modify-write traffic at B=64 disappear from the training step.
-//   * accumulation orders are the reference's (ascending candidate index per row), padding records
-//     carry zero weights and contribute exact zeros.
+//   * candidates are stored as PAIR records ([x0 x1 | y0 y1 | z0 z1 | w0 w1 ...]) so that the distance and
+//     weighting arithmetic of two candidates runs on packed fp32 VALU ops (v_pk_add/mul/fma_f32 with an SGPR
+//     pair as one operand) — the non-packed VALU rate is only half of the 157 TFLOP/s vector peak.  Each
+//     element still sees the reference's operation sequence (same fma chain, mul-then-add, ascending
+//     candidate order in the accumulators), so results are unchanged bit for bit.
+//   * padding records carry zero weights and contribute exact zeros.
 #include "hp_common.h"
 #include <algorithm>
 
@@ -26,12 +30,13 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kLevels = 9;
-constexpr int kStage = 8;   // candidate records per software-pipeline stage of the phase kernels
-constexpr int kSpare = 8;   // readable zero records past the padded range (the prefetch after the last stage)
+constexpr int kStage = 8;   // candidates per software-pipeline stage of the phase kernels (= 4 pair records)
+constexpr int kSpare = 8;   // readable zero candidates past the padded range (the prefetch after the last stage)
 constexpr float kLog2e = 1.4426950408889634f;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 // Scalar-memory loads the compiler must neither wait for early nor sink (cdna_hip_programming.md §5.7):
 // issue -> sched_barrier -> VALU work on the other stage -> one s_waitcnt that names every destination.
@@ -47,22 +52,25 @@ __host__ __device__ constexpr float level_l2e(int lev) {
 
 inline int pad_up(int x) { return (x + 2 * kStage - 1) / (2 * kStage) * (2 * kStage); }
 
-// per-cloud workspace (floats): PL4[(NP+S)*4] | PR4[(MP+S)*4] | RR[MP+S] | FL16[(NP+S)*16] | FR16[(MP+S)*16]
-//   PL4 = (p.xyz, ratioL)   PR4 = (q.xyz, ratioR)   RR = remainR   F*16 = (xyz, r[level 0..8], 0,0,0,0)
+// per-cloud workspace (floats), every candidate array padded to NP/MP (+kSpare) entries:
+//   PLP  pair records of set1 for phase 2:        8 floats per PAIR  [x0 x1 y0 y1 z0 z1 ratioL0 ratioL1]
+//   PRP  pair records of set2 for phases 1/3:     8 floats per PAIR  [x0 x1 y0 y1 z0 z1 ratioR0 ratioR1]
+//   RR   remainR per candidate of set2 (linear, so pairs are adjacent)
+//   FLP / FRP  "final" pair records (32 floats per PAIR): [x0 x1 y0 y1 z0 z1 | r(lev0)0 r(lev0)1 | ... | r(lev8)0 r(lev8)1 | 8 pad]
 struct WsLayout {
     int NP, MP;
-    long pl4, pr4, rr, fl16, fr16, per_cloud;
+    long plp, prp, rr, flp, frp, per_cloud;
 };
 inline WsLayout ws_layout(int n, int m) {
     WsLayout w;
     w.NP = pad_up(n);
     w.MP = pad_up(m);
-    w.pl4 = 0;
-    w.pr4 = w.pl4 + (long)(w.NP + kSpare) * 4;
-    w.rr = w.pr4 + (long)(w.MP + kSpare) * 4;
-    w.fl16 = w.rr + (long)(w.MP + kSpare);
-    w.fr16 = w.fl16 + (long)(w.NP + kSpare) * 16;
-    w.per_cloud = w.fr16 + (long)(w.MP + kSpare) * 16;
+    w.plp = 0;
+    w.prp = w.plp + (long)(w.NP + kSpare) * 4;
+    w.rr = w.prp + (long)(w.MP + kSpare) * 4;
+    w.flp = w.rr + (long)(w.MP + kSpare);
+    w.frp = w.flp + (long)(w.NP + kSpare) * 16;
+    w.per_cloud = w.frp + (long)(w.MP + kSpare) * 16;
     return w;
 }
 
@@ -72,8 +80,12 @@ struct Ctx {
     const float* xyz2;
     float* temp;  // (b, 2(n+m)) : [remainL n | remainR m | ratioL n | ratioR m]  (reference layout, approxmatch.cu:35)
     float* ws;
-    long pl4, pr4, rr, fl16, fr16, per_cloud;
+    long plp, prp, rr, flp, frp, per_cloud;
 };
+
+// element offsets of candidate i inside the pair-record arrays
+__device__ __forceinline__ long pair8(int i, int comp) { return (long)(i >> 1) * 8 + comp * 2 + (i & 1); }            // comp 0..3 = x,y,z,w
+__device__ __forceinline__ long pair32(int i, int comp) { return (long)(i >> 1) * 32 + comp * 2 + (i & 1); }          // comp 0..2 = x,y,z ; 3+lev = ratio
 
 __global__ __launch_bounds__(kThreads) void emd_init_kernel(Ctx c, float multiL, float multiR) {
     const int cloud = blockIdx.y;
@@ -83,35 +95,46 @@ __global__ __launch_bounds__(kThreads) void emd_init_kernel(Ctx c, float multiL,
     const float* P = c.xyz1 + (long)cloud * c.n * 3;
     const float* Q = c.xyz2 + (long)cloud * c.m * 3;
     const int NPs = c.NP + kSpare, MPs = c.MP + kSpare;
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < NPs + MPs; i += gridDim.x * kThreads) {
-        if (i < NPs) {
-            const bool ok = i < c.n;
-            const float4 r = ok ? make_float4(P[i * 3], P[i * 3 + 1], P[i * 3 + 2], 0.f) : zero;
-            reinterpret_cast<float4*>(ws + c.pl4)[i] = r;
-            float4* f = reinterpret_cast<float4*>(ws + c.fl16) + (long)i * 4;
-            f[0] = r;
-            f[1] = f[2] = f[3] = zero;
-            if (ok) remL[i] = multiL;
+        const bool left = i < NPs;
+        const int j = left ? i : i - NPs;
+        const bool ok = j < (left ? c.n : c.m);
+        const float* src = left ? P : Q;
+        const float x = ok ? src[j * 3] : 0.f, y = ok ? src[j * 3 + 1] : 0.f, z = ok ? src[j * 3 + 2] : 0.f;
+        float* p8 = ws + (left ? c.plp : c.prp);
+        float* p32 = ws + (left ? c.flp : c.frp);
+        p8[pair8(j, 0)] = x;
+        p8[pair8(j, 1)] = y;
+        p8[pair8(j, 2)] = z;
+        p8[pair8(j, 3)] = 0.f;
+        p32[pair32(j, 0)] = x;
+        p32[pair32(j, 1)] = y;
+        p32[pair32(j, 2)] = z;
+#pragma unroll
+        for (int q = 3; q < 16; ++q) p32[pair32(j, q)] = 0.f;
+        if (left) {
+            if (ok) remL[j] = multiL;
         } else {
-            const int l = i - NPs;
-            const bool ok = l < c.m;
-            const float4 r = ok ? make_float4(Q[l * 3], Q[l * 3 + 1], Q[l * 3 + 2], 0.f) : zero;
-            reinterpret_cast<float4*>(ws + c.pr4)[l] = r;
-            ws[c.rr + l] = ok ? multiR : 0.f;
-            float4* f = reinterpret_cast<float4*>(ws + c.fr16) + (long)l * 4;
-            f[0] = r;
-            f[1] = f[2] = f[3] = zero;
-            if (ok) remR[l] = multiR;
+            ws[c.rr + j] = ok ? multiR : 0.f;
+            if (ok) remR[j] = multiR;
         }
     }
 }
 
-// component `c` of record `u` (0..7) of a stage held in two x16 SGPR groups
-#define REC(lo, hi, u, c) ((u) < 4 ? (lo)[(u)*4 + (c)] : (hi)[((u)-4) * 4 + (c)])
+// pair record `u` (0..3) of a stage held in two x16 SGPR groups: component c (0=x,1=y,2=z,3=w) as a float2
+// (indices are compile-time constants once the stage loop is unrolled; elements (2i, 2i+1) form an aligned SGPR pair)
+#define PAIRC(lo, hi, u, c) \
+    ((u) < 2 ? f2{(lo)[(u)*8 + (c)*2], (lo)[(u)*8 + (c)*2 + 1]} : f2{(hi)[((u)-2) * 8 + (c)*2], (hi)[((u)-2) * 8 + (c)*2 + 1]})
+
+__device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
+// squared distances of a candidate pair to the lane's point: per element fma(dz,dz,fma(dy,dy,dx*dx))
+__device__ __forceinline__ f2 sqdist2(f2 dx, f2 dy, f2 dz) {
+    return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+}
+__device__ __forceinline__ f2 exp2_2(f2 a) { return f2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)}; }
 
 // Rows = set1.  DO3: phase 3 of level lev3 (remainL update, approxmatch.cu:161-194);
-//               DO1: phase 1 of level lev1 (ratioL, :60-93).  Candidates: PR4 (+RR) records on the scalar path.
+//               DO1: phase 1 of level lev1 (ratioL, :60-93).  Candidates: PRP (+RR) records on the scalar path.
 template <bool DO3, bool DO1>
 __global__ __launch_bounds__(kThreads) void emd_rows1_kernel(Ctx c, int lev1, float l2e3, float l2e1) {
     const int cloud = blockIdx.y;
@@ -128,17 +151,26 @@ __global__ __launch_bounds__(kThreads) void emd_rows1_kernel(Ctx c, int lev1, fl
         pz = s[2];
         if (DO3) rl = ratioL[k];
     }
+    const f2 px2 = splat(px), py2 = splat(py), pz2 = splat(pz), rl2 = splat(rl), l3 = splat(l2e3), l1 = splat(l2e1);
     float acc3 = 0.f, acc1 = 1e-9f;
-    const float* p = ws + c.pr4;   // wave-uniform
+    const float* p = ws + c.prp;   // wave-uniform
     const float* q = ws + c.rr;
     f32x16 a0, a1, b0, b1;
     f32x8 w0 = {}, w1 = {};
     auto work = [&](const f32x16& lo, const f32x16& hi, const f32x8& w) {
 #pragma unroll
-        for (int u = 0; u < kStage; ++u) {
-            const float d = hp::sqdist(REC(lo, hi, u, 0) - px, REC(lo, hi, u, 1) - py, REC(lo, hi, u, 2) - pz);
-            if (DO3) acc3 += (__builtin_amdgcn_exp2f(l2e3 * d) * rl) * REC(lo, hi, u, 3);   // e * ratioL[k] * ratioR[l]
-            if (DO1) acc1 += __builtin_amdgcn_exp2f(l2e1 * d) * w[u];                      // e * remainR[l]
+        for (int u = 0; u < kStage / 2; ++u) {
+            const f2 d = sqdist2(PAIRC(lo, hi, u, 0) - px2, PAIRC(lo, hi, u, 1) - py2, PAIRC(lo, hi, u, 2) - pz2);
+            if (DO3) {
+                const f2 t = (exp2_2(l3 * d) * rl2) * PAIRC(lo, hi, u, 3);   // (e * ratioL[k]) * ratioR[l]
+                acc3 += t.x;
+                acc3 += t.y;
+            }
+            if (DO1) {
+                const f2 t = exp2_2(l1 * d) * f2{w[u * 2], w[u * 2 + 1]};   // e * remainR[l]
+                acc1 += t.x;
+                acc1 += t.y;
+            }
         }
     };
     HP_SLOAD16(a0, p, 0x0);
@@ -172,12 +204,12 @@ __global__ __launch_bounds__(kThreads) void emd_rows1_kernel(Ctx c, int lev1, fl
     if (DO1) {
         const float v = rem / acc1;
         ratioL[k] = v;
-        ws[c.pl4 + (long)k * 4 + 3] = v;
-        ws[c.fl16 + (long)k * 16 + 3 + lev1] = v;
+        ws[c.plp + pair8(k, 3)] = v;
+        ws[c.flp + pair32(k, 3 + lev1)] = v;
     }
 }
 
-// Rows = set2: phase 2 (ratioR / remainR update, approxmatch.cu:109-142).  Candidates: PL4 records.
+// Rows = set2: phase 2 (ratioR / remainR update, approxmatch.cu:109-142).  Candidates: PLP records.
 __global__ __launch_bounds__(kThreads) void emd_rows2_kernel(Ctx c, int lev, float l2e) {
     const int cloud = blockIdx.y;
     const int l = blockIdx.x * kThreads + threadIdx.x;
@@ -192,15 +224,18 @@ __global__ __launch_bounds__(kThreads) void emd_rows2_kernel(Ctx c, int lev, flo
         qy = s[1];
         qz = s[2];
     }
+    const f2 qx2 = splat(qx), qy2 = splat(qy), qz2 = splat(qz), lv = splat(l2e);
     float acc = 0.f;
-    const float* p = ws + c.pl4;
+    const float* p = ws + c.plp;
     f32x16 a0, a1, b0, b1;
     auto work = [&](const f32x16& lo, const f32x16& hi) {
 #pragma unroll
-        for (int u = 0; u < kStage; ++u) {
+        for (int u = 0; u < kStage / 2; ++u) {
             // the reference evaluates (x2-x1) with x2 the set2 point in every phase (approxmatch.cu:85,131,185)
-            const float d = hp::sqdist(qx - REC(lo, hi, u, 0), qy - REC(lo, hi, u, 1), qz - REC(lo, hi, u, 2));
-            acc += __builtin_amdgcn_exp2f(l2e * d) * REC(lo, hi, u, 3);
+            const f2 d = sqdist2(qx2 - PAIRC(lo, hi, u, 0), qy2 - PAIRC(lo, hi, u, 1), qz2 - PAIRC(lo, hi, u, 2));
+            const f2 t = exp2_2(lv * d) * PAIRC(lo, hi, u, 3);
+            acc += t.x;
+            acc += t.y;
         }
     };
     HP_SLOAD16(a0, p, 0x0);
@@ -228,23 +263,35 @@ __global__ __launch_bounds__(kThreads) void emd_rows2_kernel(Ctx c, int lev, flo
     const float rem = fmaxf(0.0f, rr - sumr);
     ratioR[l] = v;
     remR[l] = rem;
-    ws[c.pr4 + (long)l * 4 + 3] = v;
+    ws[c.prp + pair8(l, 3)] = v;
     ws[c.rr + l] = rem;
-    ws[c.fr16 + (long)l * 16 + 3 + lev] = v;
+    ws[c.frp + pair32(l, 3 + lev)] = v;
 }
 
-// M(l,k) = sum over levels, in level order, of (exp(level*d) * ratioL_lev[k]) * ratioR_lev[l].
-// `row` holds the lane's own final record in VGPRs, `cand` the candidate's record in SGPRs; ROW_IS_L says which
-// of the two carries the ratioL values.
+// final pair record (two x16 SGPR groups): component q (0..2 xyz, 3+lev ratio) as a float2
+#define FINC(lo, hi, q) ((q) < 8 ? f2{(lo)[(q)*2], (lo)[(q)*2 + 1]} : f2{(hi)[((q)-8) * 2], (hi)[((q)-8) * 2 + 1]})
+
+// M(l,k) for the two candidates of a pair record = sum over levels, in level order, of
+//   ROW_IS_L: (exp(level*d) * ratioL_lev[row]) * ratioR_lev[cand]     (row = set1 point, candidates = set2)
+//   else    : (exp(level*d) * ratioL_lev[cand]) * ratioR_lev[row]
 template <bool ROW_IS_L>
-__device__ __forceinline__ float match_entry(float d, const float (&row)[kLevels], const f32x16& cand) {
-    float acc = 0.f;
+__device__ __forceinline__ f2 match_entry2(f2 d, const float (&row)[kLevels], const f32x16& lo, const f32x16& hi) {
+    f2 acc = splat(0.f);
 #pragma unroll
     for (int lev = 0; lev < kLevels; ++lev) {
-        const float e = __builtin_amdgcn_exp2f(level_l2e(lev) * d);
-        acc += ROW_IS_L ? (e * row[lev]) * cand[3 + lev] : (e * cand[3 + lev]) * row[lev];
+        const f2 e = exp2_2(splat(level_l2e(lev)) * d);
+        const f2 cr = FINC(lo, hi, 3 + lev);
+        acc += ROW_IS_L ? (e * splat(row[lev])) * cr : (e * cr) * splat(row[lev]);
     }
     return acc;
+}
+
+__device__ __forceinline__ void load_row_final(const float* rec, int i, float& x, float& y, float& z, float (&r)[kLevels]) {
+    x = rec[pair32(i, 0)];
+    y = rec[pair32(i, 1)];
+    z = rec[pair32(i, 2)];
+#pragma unroll
+    for (int lev = 0; lev < kLevels; ++lev) r[lev] = rec[pair32(i, 3 + lev)];
 }
 
 constexpr int kLT = 64;  // match rows (l) per workgroup in the materialising pass
@@ -255,32 +302,36 @@ __global__ __launch_bounds__(kThreads) void emd_match_kernel(Ctx c, float* __res
     const float* ws = c.ws + (long)cloud * c.per_cloud;
     const bool ok = k < c.n;
     float px = 0.f, py = 0.f, pz = 0.f, rL[kLevels] = {};
-    if (ok) {
-        const float* fl = ws + c.fl16 + (long)k * 16;
-        px = fl[0];
-        py = fl[1];
-        pz = fl[2];
-#pragma unroll
-        for (int lev = 0; lev < kLevels; ++lev) rL[lev] = fl[3 + lev];
-    }
+    if (ok) load_row_final(ws + c.flp, k, px, py, pz, rL);
+    const f2 px2 = splat(px), py2 = splat(py), pz2 = splat(pz);
     float* out = match + ((long)cloud * c.m + l0) * c.n + k;
-    const int cnt = min(kLT, c.m - l0);          // kLT and MP are multiples of 2, spare records exist past MP
-    const float* p = ws + c.fr16 + (long)l0 * 16;
-    f32x16 a, b;
-    HP_SLOAD16(a, p, 0x0);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a));
-    for (int l = 0; l < cnt; l += 2) {
-        HP_SLOAD16(b, p, 0x40);
-        HP_PIN();
-        float v = match_entry<true>(hp::sqdist(a[0] - px, a[1] - py, a[2] - pz), rL, a);
-        if (ok) out[(long)l * c.n] = v;
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b), "+v"(v));
+    const int cnt = min(kLT, c.m - l0);          // l0 is even; spare records exist past MP
+    const float* p = ws + c.frp + (long)(l0 >> 1) * 32;
+    f32x16 a0, a1, b0, b1;
+    HP_SLOAD16(a0, p, 0x0);
+    HP_SLOAD16(a1, p, 0x40);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1));
+    for (int l = 0; l < cnt; l += 4) {
         p += 32;
-        HP_SLOAD16(a, p, 0x0);
+        HP_SLOAD16(b0, p, 0x0);
+        HP_SLOAD16(b1, p, 0x40);
         HP_PIN();
-        v = match_entry<true>(hp::sqdist(b[0] - px, b[1] - py, b[2] - pz), rL, b);
-        if (ok && l + 1 < cnt) out[(long)(l + 1) * c.n] = v;
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+v"(v));
+        f2 v = match_entry2<true>(sqdist2(FINC(a0, a1, 0) - px2, FINC(a0, a1, 1) - py2, FINC(a0, a1, 2) - pz2), rL, a0, a1);
+        if (ok) {
+            out[(long)l * c.n] = v.x;
+            if (l + 1 < cnt) out[(long)(l + 1) * c.n] = v.y;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1), "+v"(v));
+        p += 32;
+        HP_SLOAD16(a0, p, 0x0);
+        HP_SLOAD16(a1, p, 0x40);
+        HP_PIN();
+        v = match_entry2<true>(sqdist2(FINC(b0, b1, 0) - px2, FINC(b0, b1, 1) - py2, FINC(b0, b1, 2) - pz2), rL, b0, b1);
+        if (ok && l + 2 < cnt) {
+            out[(long)(l + 2) * c.n] = v.x;
+            if (l + 3 < cnt) out[(long)(l + 3) * c.n] = v.y;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(v));
     }
 }
 
@@ -293,39 +344,41 @@ __global__ __launch_bounds__(kThreads) void emd_cost_grad1_kernel(Ctx c, float* 
     const float* ws = c.ws + (long)cloud * c.per_cloud;
     const bool ok = k < c.n;
     float px = 0.f, py = 0.f, pz = 0.f, rL[kLevels] = {};
-    if (ok) {
-        const float* fl = ws + c.fl16 + (long)k * 16;
-        px = fl[0];
-        py = fl[1];
-        pz = fl[2];
-#pragma unroll
-        for (int lev = 0; lev < kLevels; ++lev) rL[lev] = fl[3 + lev];
-    }
+    if (ok) load_row_final(ws + c.flp, k, px, py, pz, rL);
+    const f2 px2 = splat(px), py2 = splat(py), pz2 = splat(pz);
     float cost = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
-    auto work = [&](const f32x16& r) {
-        const float ex = px - r[0], ey = py - r[1], ez = pz - r[2];   // (x1 - x2), approxmatch.cu:312
-        const float d2 = hp::sqdist(r[0] - px, r[1] - py, r[2] - pz);
-        const float mv = match_entry<true>(d2, rL, r);
-        cost = __builtin_fmaf(mv, __builtin_sqrtf(d2), cost);
-        const float w = mv * __builtin_amdgcn_rsqf(fmaxf(d2, 1e-20f));
-        dx = __builtin_fmaf(ex, w, dx);
-        dy = __builtin_fmaf(ey, w, dy);
-        dz = __builtin_fmaf(ez, w, dz);
+    auto work = [&](const f32x16& lo, const f32x16& hi) {
+        const f2 ex = px2 - FINC(lo, hi, 0), ey = py2 - FINC(lo, hi, 1), ez = pz2 - FINC(lo, hi, 2);   // (x1 - x2), approxmatch.cu:312
+        const f2 d2 = sqdist2(ex, ey, ez);       // squares: the sign of the difference does not change a bit
+        const f2 mv = match_entry2<true>(d2, rL, lo, hi);
+        const f2 w = mv * f2{__builtin_amdgcn_rsqf(fmaxf(d2.x, 1e-20f)), __builtin_amdgcn_rsqf(fmaxf(d2.y, 1e-20f))};
+        cost = __builtin_fmaf(mv.x, __builtin_amdgcn_sqrtf(d2.x), cost);
+        cost = __builtin_fmaf(mv.y, __builtin_amdgcn_sqrtf(d2.y), cost);
+        dx = __builtin_fmaf(ex.x, w.x, dx);
+        dx = __builtin_fmaf(ex.y, w.y, dx);
+        dy = __builtin_fmaf(ey.x, w.x, dy);
+        dy = __builtin_fmaf(ey.y, w.y, dy);
+        dz = __builtin_fmaf(ez.x, w.x, dz);
+        dz = __builtin_fmaf(ez.y, w.y, dz);
     };
-    const float* p = ws + c.fr16;
-    f32x16 a, b;
-    HP_SLOAD16(a, p, 0x0);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a));
-    for (int l = 0; l < c.MP; l += 2) {
-        HP_SLOAD16(b, p, 0x40);
-        HP_PIN();
-        work(a);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b), "+v"(cost), "+v"(dx), "+v"(dy), "+v"(dz));
+    const float* p = ws + c.frp;
+    f32x16 a0, a1, b0, b1;
+    HP_SLOAD16(a0, p, 0x0);
+    HP_SLOAD16(a1, p, 0x40);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1));
+    for (int l = 0; l < c.MP; l += 4) {
         p += 32;
-        HP_SLOAD16(a, p, 0x0);
+        HP_SLOAD16(b0, p, 0x0);
+        HP_SLOAD16(b1, p, 0x40);
         HP_PIN();
-        work(b);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+v"(cost), "+v"(dx), "+v"(dy), "+v"(dz));
+        work(a0, a1);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1), "+v"(cost), "+v"(dx), "+v"(dy), "+v"(dz));
+        p += 32;
+        HP_SLOAD16(a0, p, 0x0);
+        HP_SLOAD16(a1, p, 0x40);
+        HP_PIN();
+        work(b0, b1);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(cost), "+v"(dx), "+v"(dy), "+v"(dz));
     }
     if (ok && grad1) {
         float* g = grad1 + ((long)cloud * c.n + k) * 3;
@@ -344,38 +397,39 @@ __global__ __launch_bounds__(kThreads) void emd_grad2_kernel(Ctx c, float* __res
     const float* ws = c.ws + (long)cloud * c.per_cloud;
     const bool ok = l < c.m;
     float qx = 0.f, qy = 0.f, qz = 0.f, rR[kLevels] = {};
-    if (ok) {
-        const float* fr = ws + c.fr16 + (long)l * 16;
-        qx = fr[0];
-        qy = fr[1];
-        qz = fr[2];
-#pragma unroll
-        for (int lev = 0; lev < kLevels; ++lev) rR[lev] = fr[3 + lev];
-    }
+    if (ok) load_row_final(ws + c.frp, l, qx, qy, qz, rR);
+    const f2 qx2 = splat(qx), qy2 = splat(qy), qz2 = splat(qz);
     float sx = 0.f, sy = 0.f, sz = 0.f;
-    auto work = [&](const f32x16& r) {
-        const float ex = qx - r[0], ey = qy - r[1], ez = qz - r[2];
-        const float d2 = hp::sqdist(ex, ey, ez);
-        const float mv = match_entry<false>(d2, rR, r);
-        const float w = mv * __builtin_amdgcn_rsqf(fmaxf(d2, 1e-20f));
-        sx = __builtin_fmaf(ex, w, sx);
-        sy = __builtin_fmaf(ey, w, sy);
-        sz = __builtin_fmaf(ez, w, sz);
+    auto work = [&](const f32x16& lo, const f32x16& hi) {
+        const f2 ex = qx2 - FINC(lo, hi, 0), ey = qy2 - FINC(lo, hi, 1), ez = qz2 - FINC(lo, hi, 2);
+        const f2 d2 = sqdist2(ex, ey, ez);
+        const f2 mv = match_entry2<false>(d2, rR, lo, hi);
+        const f2 w = mv * f2{__builtin_amdgcn_rsqf(fmaxf(d2.x, 1e-20f)), __builtin_amdgcn_rsqf(fmaxf(d2.y, 1e-20f))};
+        sx = __builtin_fmaf(ex.x, w.x, sx);
+        sx = __builtin_fmaf(ex.y, w.y, sx);
+        sy = __builtin_fmaf(ey.x, w.x, sy);
+        sy = __builtin_fmaf(ey.y, w.y, sy);
+        sz = __builtin_fmaf(ez.x, w.x, sz);
+        sz = __builtin_fmaf(ez.y, w.y, sz);
     };
-    const float* p = ws + c.fl16;
-    f32x16 a, b;
-    HP_SLOAD16(a, p, 0x0);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a));
-    for (int k = 0; k < c.NP; k += 2) {
-        HP_SLOAD16(b, p, 0x40);
-        HP_PIN();
-        work(a);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b), "+v"(sx), "+v"(sy), "+v"(sz));
+    const float* p = ws + c.flp;
+    f32x16 a0, a1, b0, b1;
+    HP_SLOAD16(a0, p, 0x0);
+    HP_SLOAD16(a1, p, 0x40);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1));
+    for (int k = 0; k < c.NP; k += 4) {
         p += 32;
-        HP_SLOAD16(a, p, 0x0);
+        HP_SLOAD16(b0, p, 0x0);
+        HP_SLOAD16(b1, p, 0x40);
         HP_PIN();
-        work(b);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+v"(sx), "+v"(sy), "+v"(sz));
+        work(a0, a1);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1), "+v"(sx), "+v"(sy), "+v"(sz));
+        p += 32;
+        HP_SLOAD16(a0, p, 0x0);
+        HP_SLOAD16(a1, p, 0x40);
+        HP_PIN();
+        work(b0, b1);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(sx), "+v"(sy), "+v"(sz));
     }
     if (!ok) return;
     float* g = grad2 + ((long)cloud * c.m + l) * 3;
@@ -395,7 +449,7 @@ __global__ __launch_bounds__(256) void emd_cost_finish_kernel(const float* __res
 
 int run_levels(int b, int n, int m, const float* xyz1, const float* xyz2, float* temp, float* ws, Ctx* out, hipStream_t stream) {
     const WsLayout L = ws_layout(n, m);
-    Ctx c{n, m, L.NP, L.MP, xyz1, xyz2, temp, ws, L.pl4, L.pr4, L.rr, L.fl16, L.fr16, L.per_cloud};
+    Ctx c{n, m, L.NP, L.MP, xyz1, xyz2, temp, ws, L.plp, L.prp, L.rr, L.flp, L.frp, L.per_cloud};
     float multiL, multiR;
     if (n >= m) {
         multiL = 1;
@@ -465,7 +519,7 @@ HP_API int hp_emd_backward(int b, int n, int m, const float* xyz1, const float* 
     if (b == 0) return 0;
     HP_CHECK_ARG(ws && grad2 && b <= 65535);
     const WsLayout L = ws_layout(n, m);
-    Ctx c{n, m, L.NP, L.MP, xyz1, xyz2, nullptr, const_cast<float*>(ws), L.pl4, L.pr4, L.rr, L.fl16, L.fr16, L.per_cloud};
+    Ctx c{n, m, L.NP, L.MP, xyz1, xyz2, nullptr, const_cast<float*>(ws), L.plp, L.prp, L.rr, L.flp, L.frp, L.per_cloud};
     hipLaunchKernelGGL(emd_grad2_kernel, dim3((m + kThreads - 1) / kThreads, b), dim3(kThreads), 0, stream, c, grad2);
     HP_RETURN_LAST_ERROR();
 }
