@@ -50,6 +50,9 @@ struct KParams {
     int flags;
     int vecA, vecB;
     int tiles_m, tiles_n;
+    float* cmax;
+    int* cidx;
+    int group_rows;
 };
 
 __device__ __forceinline__ float4 ld4(const float* __restrict__ base, long rowoff, int k, long s_k, bool row_ok, int kend, bool vec) {
@@ -210,6 +213,55 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const KParams p) {
     }
 
     // epilogue.  C/D map of the 32x32 f32 tile: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    if (p.flags & HP_GEMM_COLMAX) {
+        // fused max-pool over this tile's rows (model/encoder.py:45): first row attaining the max wins
+        __shared__ float smax[WGM][BN];
+        __shared__ int sidx[WGM][BN];
+        const float* bias = (p.flags & HP_GEMM_BIAS) ? p.bias : nullptr;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int cl = wn * WN + j * 32 + r;
+            const int col = col0 + cl;
+            const float bv = (bias && col < p.N) ? bias[col] : 0.f;
+            float best = -__builtin_inff();
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {   // rows ascend with (i, e) for a fixed lane half
+                    const int row = row0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const float v = acc[i][j][e] + bv;
+                    if (row < p.M && v > best) {
+                        best = v;
+                        bi = row;
+                    }
+                }
+            const float ov = __shfl_xor(best, 32, 64);
+            const int oi = __shfl_xor(bi, 32, 64);
+            if (ov > best || (ov == best && oi < bi)) {
+                best = ov;
+                bi = oi;
+            }
+            if (h == 0) {
+                smax[wm][cl] = best;
+                sidx[wm][cl] = bi;
+            }
+        }
+        __syncthreads();
+        if (tid < BN && col0 + tid < p.N) {
+            float best = smax[0][tid];
+            int bi = sidx[0][tid];
+#pragma unroll
+            for (int q = 1; q < WGM; ++q)
+                if (smax[q][tid] > best) {   // later wave rows are larger: strict > keeps the first row
+                    best = smax[q][tid];
+                    bi = sidx[q][tid];
+                }
+            p.cmax[(long)tile_m * p.N + col0 + tid] = best;
+            p.cidx[(long)tile_m * p.N + col0 + tid] = bi % p.group_rows;
+        }
+        return;
+    }
     const bool partial = p.ksplit > 1;
     float* C = partial ? p.ws + ((long)blockIdx.y) * p.M * p.N : p.C + (long)z * p.sCz;
     const int ldc = partial ? p.N : p.ldc;
@@ -331,6 +383,19 @@ int launch_cfg(KParams& p, int batch, hipStream_t stream) {
 
 inline bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
+// Tile choice: the largest tile that still yields >= ~2 workgroups per CU; skinny problems (M <= 64, the
+// hypernetwork's B x 19011 heads) and small ones fall through to smaller tiles instead of idling CUs.
+// 0: 128x32, 1: 128x128, 2: 64x128, 3: 64x64
+constexpr int kCfgRows[4] = {128, 128, 64, 64};
+int choose_cfg(const HpGemmDesc* d, int ksplit) {
+    const long zs = (long)d->batch * ksplit;
+    auto wgs = [&](int bm, int bn) { return (long)((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn) * zs; };
+    if (d->N <= 32) return 0;
+    if (d->M > 64 && d->N > 64 && wgs(128, 128) >= 384) return 1;
+    if (d->N > 64 && wgs(64, 128) >= 512) return 2;
+    return 3;
+}
+
 }  // namespace
 
 HP_API long hp_gemm_workspace_floats(const HpGemmDesc* d) {
@@ -338,10 +403,20 @@ HP_API long hp_gemm_workspace_floats(const HpGemmDesc* d) {
     return (long)d->batch * d->ksplit * d->M * d->N;
 }
 
+// rows per output tile hp_gemm_f32 will use for this problem (HP_GEMM_COLMAX partial layout)
+HP_API int hp_gemm_tile_rows(const HpGemmDesc* d) {
+    if (!d) return -1;
+    return kCfgRows[choose_cfg(d, d->ksplit > 1 ? d->ksplit : 1)];
+}
+
 HP_API int hp_gemm_f32(const HpGemmDesc* d, hipStream_t stream) {
     HP_CHECK_ARG(d && d->M >= 0 && d->N >= 0 && d->K >= 0 && d->batch >= 0);
     if (d->M == 0 || d->N == 0 || d->batch == 0) return 0;
-    HP_CHECK_ARG(d->A && d->B && d->C);
+    HP_CHECK_ARG(d->A && d->B && (d->C || (d->flags & HP_GEMM_COLMAX)));
+    if (d->flags & HP_GEMM_COLMAX) {
+        HP_CHECK_ARG(d->cmax && d->cidx && d->group_rows > 0 && d->batch == 1 && d->ksplit <= 1);
+        HP_CHECK_ARG(d->group_rows % hp_gemm_tile_rows(d) == 0 && d->M % d->group_rows == 0);
+    }
     HP_CHECK_ARG(d->sAi == 1 || d->sAk == 1 || d->M == 1 || d->K == 1);
     HP_CHECK_ARG(d->sBk == 1 || d->sBj == 1 || d->N == 1 || d->K == 1);
     HP_CHECK_ARG(!(d->flags & HP_GEMM_BIAS) || d->bias);
@@ -352,6 +427,7 @@ HP_API int hp_gemm_f32(const HpGemmDesc* d, hipStream_t stream) {
     p.A = d->A; p.B = d->B; p.C = d->C; p.bias = d->bias; p.mask = d->mask; p.add = d->add; p.ws = d->ws;
     p.sAz = d->sAz; p.sBz = d->sBz; p.sCz = d->sCz; p.sBiasz = d->sBiasz; p.sMaskz = d->sMaskz; p.sAddz = d->sAddz;
     p.ldadd = d->ldadd;
+    p.cmax = d->cmax; p.cidx = d->cidx; p.group_rows = d->group_rows;
     p.sAi = d->sAi; p.sAk = d->sAk; p.sBk = d->sBk; p.sBj = d->sBj;
     p.ldc = d->ldc; p.ldmask = d->ldmask; p.M = d->M; p.N = d->N; p.K = d->K; p.flags = d->flags;
     p.ksplit = d->ksplit > 1 ? d->ksplit : 1;
@@ -362,19 +438,13 @@ HP_API int hp_gemm_f32(const HpGemmDesc* d, hipStream_t stream) {
     p.vecA = (d->sAk == 1) && (d->sAi % 4 == 0) && (d->sAz % 4 == 0) && aligned16(d->A);
     p.vecB = (d->sBk == 1) && (d->sBj % 4 == 0) && (d->sBz % 4 == 0) && aligned16(d->B);
 
-    // Tile choice: the largest tile that still yields >= ~2 workgroups per CU; skinny problems (M <= 64, the
-    // hypernetwork's B x 19011 heads) and small ones fall through to smaller tiles instead of idling CUs.
     int rc;
-    const long zs = (long)d->batch * p.ksplit;
-    auto wgs = [&](int bm, int bn) { return (long)((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn) * zs; };
-    if (d->N <= 32)
-        rc = launch_cfg<128, 32, 4, 1, 16>(p, d->batch, stream);
-    else if (d->M > 64 && d->N > 64 && wgs(128, 128) >= 384)
-                rc = launch_cfg<128, 128, 2, 2, 16>(p, d->batch, stream);
-    else if (d->N > 64 && wgs(64, 128) >= 512)
-        rc = launch_cfg<64, 128, 2, 2, 16>(p, d->batch, stream);
-    else
-        rc = launch_cfg<64, 64, 2, 2, 16>(p, d->batch, stream);
+    switch (choose_cfg(d, p.ksplit)) {
+        case 0: rc = launch_cfg<128, 32, 4, 1, 16>(p, d->batch, stream); break;
+        case 1: rc = launch_cfg<128, 128, 2, 2, 16>(p, d->batch, stream); break;
+        case 2: rc = launch_cfg<64, 128, 2, 2, 16>(p, d->batch, stream); break;
+        default: rc = launch_cfg<64, 64, 2, 2, 16>(p, d->batch, stream); break;
+    }
     if (rc) return rc;
     if (p.ksplit > 1) {
         const long mn = (long)d->M * d->N;
@@ -388,7 +458,7 @@ HP_API int hp_gemm_f32(const HpGemmDesc* d, hipStream_t stream) {
 // hp_colsum_workspace_floats floats; without it the rows are not split across workgroups.
 HP_API long hp_colsum_workspace_floats(int batch, int M, int N) {
     (void)M;
-    return (long)batch * 128 * N;
+    return (long)batch * 32 * N;
 }
 
 HP_API int hp_colsum_f32(int batch, int M, int N, const float* X, long sXz, int ldx, const float* mask, long sMaskz,
@@ -400,7 +470,7 @@ HP_API int hp_colsum_f32(int batch, int M, int N, const float* X, long sXz, int 
     int slabs = 1;
     if (ws && M >= 512) {
         const long base = (long)colblocks * batch;
-        slabs = (int)std::min<long>(128, std::max<long>(1, std::min<long>((1024 + base - 1) / base, M / 128)));
+        slabs = (int)std::min<long>(32, std::max<long>(1, std::min<long>((768 + base - 1) / base, M / 128)));
     }
     const int rows_per_slab = (M + slabs - 1) / slabs;
     hipLaunchKernelGGL(colsum_kernel, dim3(colblocks, slabs, batch), dim3(256), 0, stream, X, sXz, ldx, M, N, mask, sMaskz,

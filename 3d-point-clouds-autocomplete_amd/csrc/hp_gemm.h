@@ -5,6 +5,7 @@
 #define HP_GEMM_RELU 2 /* max(., 0)                                   */
 #define HP_GEMM_MASK 4 /* * (mask(i,j) > 0)  — ReLU backward, fused   */
 #define HP_GEMM_ADD 8  /* + add(i,j)  (before ReLU / mask)             */
+#define HP_GEMM_COLMAX 16 /* do not store C: per row-tile column max (+bias) and its row -> cmax/cidx (fused max-pool) */
 
 typedef struct HpGemmDesc {
     const float* A;    /* A(i,k) at A + z*sAz + i*sAi + k*sAk (one of sAi,sAk is 1) */
@@ -20,4 +21,9 @@ typedef struct HpGemmDesc {
     int M, N, K, batch;
     int ksplit; /* <=1: no split */
     int flags;
+    /* HP_GEMM_COLMAX: rows come in groups of group_rows (one cloud); cmax/cidx are (M / tile_rows, N) with
+     * tile_rows = hp_gemm_tile_rows(desc) dividing group_rows; cidx holds the row index inside its group */
+    float* cmax;
+    int* cidx;
+    int group_rows;
 } HpGemmDesc;

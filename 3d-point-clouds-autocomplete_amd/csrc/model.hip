@@ -22,6 +22,7 @@
 #include <algorithm>
 
 extern "C" int hp_gemm_f32(const HpGemmDesc* d, hipStream_t stream);
+extern "C" int hp_gemm_tile_rows(const HpGemmDesc* d);
 extern "C" int hp_colsum_f32(int batch, int M, int N, const float* X, long sXz, int ldx, const float* mask, long sMaskz,
                              int ldmask, float* out, long sOz, float* ws, hipStream_t stream);
 
@@ -97,7 +98,7 @@ struct Op {
     }
     int colsum(const float* X, long sXz, int ldx, int M, int N, int batch, float* out, long sOz) const {
         // the split-K slab area doubles as the row-slab workspace (stream order keeps the uses apart)
-        const bool fits = (long)batch * 128 * N <= kSplitWs;
+        const bool fits = (long)batch * 32 * N <= kSplitWs;
         return hp_colsum_f32(batch, M, N, X, sXz, ldx, nullptr, 0, 0, out, sOz, fits ? splitws : nullptr, s);
     }
 };
@@ -140,6 +141,26 @@ __global__ __launch_bounds__(256) void colmax_kernel(const float* __restrict__ h
         g[(long)b * C + c] = best;
         arg[(long)b * C + c] = bi;
     }
+}
+
+// second stage of the fused max-pool: g[b,c] = max over the cloud's row tiles (ascending, strict >: first row wins)
+__global__ __launch_bounds__(256) void colmax_tiles_kernel(const float* __restrict__ pm, const int* __restrict__ pi, int tiles,
+                                                           int tile_rows, int C, float* __restrict__ g, int* __restrict__ arg) {
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const long base = (long)b * tiles * C + c;
+    float best = pm[base];
+    int bi = pi[base];
+    for (int t = 1; t < tiles; ++t) {
+        const float v = pm[base + (long)t * C];
+        if (v > best) {
+            best = v;
+            bi = pi[base + (long)t * C];
+        }
+    }
+    (void)tile_rows;
+    g[(long)b * C + c] = best;
+    arg[(long)b * C + c] = bi;
 }
 
 // xc[(b,c), :] = x[b, arg[b,c], :]
@@ -229,12 +250,31 @@ HP_API int hp_encoder_forward(int B, int Np, const float* x, const HpEncoderWeig
     h[1] = ws;
     for (int l = 2; l <= 5; ++l) h[l] = h[l - 1] + R * kEnc[l - 1];
     const float* in = x;
-    for (int l = 1; l <= 5; ++l) {
+    for (int l = 1; l <= 4; ++l) {
         TRY(op.lin_fwd(in, 0, kEnc[l - 1], w->conv_w[l - 1], 0, w->conv_b[l - 1], 0, h[l], 0, kEnc[l], (int)R, kEnc[l],
-                       kEnc[l - 1], 1, l < 5));
+                       kEnc[l - 1], 1, true));
         in = h[l];
     }
-    hipLaunchKernelGGL(colmax_kernel, dim3(512 / 64, B), dim3(256), 0, stream, h[5], Np, 512, g, argidx);
+    // layer 5 (no ReLU) + max over points.  When a cloud's points are whole row tiles the max-pool is fused into the
+    // GEMM epilogue: h5 (B*Np x 512) is never written; its slot in the workspace holds the per-tile partials.
+    HpGemmDesc d5{};
+    d5.A = h[4]; d5.sAi = 512; d5.sAk = 1;
+    d5.B = w->conv_w[4]; d5.sBk = 1; d5.sBj = 512;
+    d5.bias = w->conv_b[4];
+    d5.M = (int)R; d5.N = 512; d5.K = 512; d5.batch = 1;
+    d5.flags = HP_GEMM_BIAS | HP_GEMM_COLMAX;
+    d5.group_rows = Np;
+    const int tr = hp_gemm_tile_rows(&d5);
+    if (tr > 0 && Np % tr == 0) {
+        const long tiles = R / tr;
+        d5.cmax = h[5];
+        d5.cidx = reinterpret_cast<int*>(h[5] + tiles * 512);
+        TRY(hp_gemm_f32(&d5, stream));
+        hipLaunchKernelGGL(colmax_tiles_kernel, dim3(2, B), dim3(256), 0, stream, d5.cmax, d5.cidx, Np / tr, tr, 512, g, argidx);
+    } else {
+        TRY(op.lin_fwd(h[4], 0, 512, w->conv_w[4], 0, w->conv_b[4], 0, h[5], 0, 512, (int)R, 512, 512, 1, false));
+        hipLaunchKernelGGL(colmax_kernel, dim3(512 / 64, B), dim3(256), 0, stream, h[5], Np, 512, g, argidx);
+    }
     TRY(op.lin_fwd(g, 0, 512, w->fc_w, 0, w->fc_b, 0, f, 0, 512, B, 512, 512, 1, true));
     TRY(op.lin_fwd(f, 0, 512, w->mu_w, 0, w->mu_b, 0, mu, 0, out_size, B, out_size, 512, 1, false));
     if (is_vae) {

@@ -265,7 +265,8 @@ def gemm(A, B, bias=None, relu=False, trans_a=False, trans_b=True, mask=None, ad
                     ("sAz", c_long), ("sBz", c_long), ("sCz", c_long), ("sBiasz", c_long), ("sMaskz", c_long), ("sAddz", c_long),
                     ("sAi", c_long), ("sAk", c_long), ("sBk", c_long), ("sBj", c_long),
                     ("ldc", c_int), ("ldmask", c_int), ("ldadd", c_int),
-                    ("M", c_int), ("N", c_int), ("K", c_int), ("batch", c_int), ("ksplit", c_int), ("flags", c_int)]
+                    ("M", c_int), ("N", c_int), ("K", c_int), ("batch", c_int), ("ksplit", c_int), ("flags", c_int),
+                    ("cmax", c_void_p), ("cidx", c_void_p), ("group_rows", c_int)]
     batched = A.dim() == 3
     A3 = A if batched else A.unsqueeze(0)
     B3 = B if B.dim() == 3 else B.unsqueeze(0)

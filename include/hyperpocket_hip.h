@@ -87,6 +87,7 @@ int hp_chamfer_backward(int b, int n, const float* preds, int m, const float* gt
 #define HP_GEMM_RELU 2
 #define HP_GEMM_MASK 4
 #define HP_GEMM_ADD 8
+#define HP_GEMM_COLMAX 16 /* do not store C: per row-tile column max (+bias) and its row -> cmax/cidx (fused max-pool) */
 
 typedef struct HpGemmDesc {
     const float* A;    /* A(i,k) at A + z*sAz + i*sAi + k*sAk (one of sAi,sAk is 1) */
@@ -102,9 +103,15 @@ typedef struct HpGemmDesc {
     int M, N, K, batch;
     int ksplit; /* <=1: no split; >1: ordered (atomic-free) split-K through `ws` */
     int flags;
+    /* HP_GEMM_COLMAX: rows come in groups of group_rows (one cloud); cmax/cidx are (M / tile_rows, N) with
+     * tile_rows = hp_gemm_tile_rows(desc) dividing group_rows; cidx holds the row index inside its group */
+    float* cmax;
+    int* cidx;
+    int group_rows;
 } HpGemmDesc;
 
 long hp_gemm_workspace_floats(const HpGemmDesc* d);
+int hp_gemm_tile_rows(const HpGemmDesc* d);
 int hp_gemm_f32(const HpGemmDesc* d /* host struct */, hpStream_t stream);
 /* out[z][j] = sum_i (mask ? (mask(i,j)>0 ? X(i,j) : 0) : X(i,j))  — bias gradients */
 long hp_colsum_workspace_floats(int batch, int M, int N);
