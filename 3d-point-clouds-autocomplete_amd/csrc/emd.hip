@@ -390,8 +390,12 @@ __global__ __launch_bounds__(kThreads) void emd_cost_grad1_kernel(Ctx c, float* 
     if (threadIdx.x == 0) partials[(long)cloud * gridDim.x + blockIdx.x] = t;
 }
 
-// match-free grad2[l] = sum_k M(l,k) (q_l-p_k)/max(|q_l-p_k|,1e-10)   (approxmatch.cu:260-300)
-__global__ __launch_bounds__(kThreads) void emd_grad2_kernel(Ctx c, float* __restrict__ grad2) {
+// match-free grad2[l] = sum_k M(l,k) (q_l-p_k)/max(|q_l-p_k|,1e-10)   (approxmatch.cu:260-300); with WITH_COST the
+// same sweep also yields the cost (sum over the same pairs, owned by l instead of k), so a training step that only
+// needs d cost / d xyz2 evaluates the match entries once.
+template <bool WITH_COST>
+__global__ __launch_bounds__(kThreads) void emd_grad2_kernel(Ctx c, float* __restrict__ grad2, float* __restrict__ partials) {
+    __shared__ float red[kThreads / 64];
     const int cloud = blockIdx.y;
     const int l = blockIdx.x * kThreads + threadIdx.x;
     const float* ws = c.ws + (long)cloud * c.per_cloud;
@@ -399,12 +403,16 @@ __global__ __launch_bounds__(kThreads) void emd_grad2_kernel(Ctx c, float* __res
     float qx = 0.f, qy = 0.f, qz = 0.f, rR[kLevels] = {};
     if (ok) load_row_final(ws + c.frp, l, qx, qy, qz, rR);
     const f2 qx2 = splat(qx), qy2 = splat(qy), qz2 = splat(qz);
-    float sx = 0.f, sy = 0.f, sz = 0.f;
+    float sx = 0.f, sy = 0.f, sz = 0.f, cost = 0.f;
     auto work = [&](const f32x16& lo, const f32x16& hi) {
         const f2 ex = qx2 - FINC(lo, hi, 0), ey = qy2 - FINC(lo, hi, 1), ez = qz2 - FINC(lo, hi, 2);
         const f2 d2 = sqdist2(ex, ey, ez);
         const f2 mv = match_entry2<false>(d2, rR, lo, hi);
         const f2 w = mv * f2{__builtin_amdgcn_rsqf(fmaxf(d2.x, 1e-20f)), __builtin_amdgcn_rsqf(fmaxf(d2.y, 1e-20f))};
+        if (WITH_COST) {
+            cost = __builtin_fmaf(mv.x, __builtin_amdgcn_sqrtf(d2.x), cost);
+            cost = __builtin_fmaf(mv.y, __builtin_amdgcn_sqrtf(d2.y), cost);
+        }
         sx = __builtin_fmaf(ex.x, w.x, sx);
         sx = __builtin_fmaf(ex.y, w.y, sx);
         sy = __builtin_fmaf(ey.x, w.x, sy);
@@ -423,19 +431,24 @@ __global__ __launch_bounds__(kThreads) void emd_grad2_kernel(Ctx c, float* __res
         HP_SLOAD16(b1, p, 0x40);
         HP_PIN();
         work(a0, a1);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1), "+v"(sx), "+v"(sy), "+v"(sz));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1), "+v"(sx), "+v"(sy), "+v"(sz), "+v"(cost));
         p += 32;
         HP_SLOAD16(a0, p, 0x0);
         HP_SLOAD16(a1, p, 0x40);
         HP_PIN();
         work(b0, b1);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(sx), "+v"(sy), "+v"(sz));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(sx), "+v"(sy), "+v"(sz), "+v"(cost));
     }
-    if (!ok) return;
-    float* g = grad2 + ((long)cloud * c.m + l) * 3;
-    g[0] = sx;
-    g[1] = sy;
-    g[2] = sz;
+    if (ok) {
+        float* g = grad2 + ((long)cloud * c.m + l) * 3;
+        g[0] = sx;
+        g[1] = sy;
+        g[2] = sz;
+    }
+    if (WITH_COST) {
+        const float t = hp::block_sum(ok ? cost : 0.f, red);
+        if (threadIdx.x == 0) partials[(long)cloud * gridDim.x + blockIdx.x] = t;
+    }
 }
 
 __global__ __launch_bounds__(256) void emd_cost_finish_kernel(const float* __restrict__ partials, int per_cloud, float* __restrict__ out) {
@@ -496,19 +509,28 @@ HP_API int hp_approxmatch(int b, int n, int m, const float* xyz1, const float* x
 // Match-free EMD forward (what match_cost's forward = ApproxMatch + MatchCost computes, match_cost.py:9-27):
 // cost (b,) and, as a by-product of the same sweep, grad1 = d cost / d xyz1 (b,n,3) (may be NULL).
 // `ws` keeps the packed records for hp_emd_backward; partials: b*ceil(n/256) floats.
-HP_API long hp_emd_partials_floats(int b, int n) { return (long)b * ((n + kThreads - 1) / kThreads); }
+HP_API long hp_emd_partials_floats(int b, int n, int m) { return (long)b * ((std::max(n, m) + kThreads - 1) / kThreads); }
 
+// grad1 / grad2 (either may be NULL): gradients to produce in the same call.  With grad2 != NULL the cost rides on the
+// grad2 sweep (one evaluation of the match entries serves both); grad1 then costs a second sweep only if requested.
 HP_API int hp_emd_forward(int b, int n, int m, const float* xyz1, const float* xyz2, float* temp, float* ws, float* partials,
-                          float* cost, float* grad1, hipStream_t stream) {
+                          float* cost, float* grad1, float* grad2, hipStream_t stream) {
     HP_CHECK_ARG(b >= 0 && n > 0 && m > 0);
     if (b == 0) return 0;
     HP_CHECK_ARG(xyz1 && xyz2 && temp && ws && partials && cost && b <= 65535);
     Ctx c;
     int rc = run_levels(b, n, m, xyz1, xyz2, temp, ws, &c, stream);
     if (rc) return rc;
-    const int nb = (n + kThreads - 1) / kThreads;
-    hipLaunchKernelGGL(emd_cost_grad1_kernel, dim3(nb, b), dim3(kThreads), 0, stream, c, partials, grad1);
-    hipLaunchKernelGGL(emd_cost_finish_kernel, dim3(b), dim3(256), 0, stream, partials, nb, cost);
+    const int nb = (n + kThreads - 1) / kThreads, mb = (m + kThreads - 1) / kThreads;
+    if (grad2) {
+        hipLaunchKernelGGL(emd_grad2_kernel<true>, dim3(mb, b), dim3(kThreads), 0, stream, c, grad2, partials);
+        hipLaunchKernelGGL(emd_cost_finish_kernel, dim3(b), dim3(256), 0, stream, partials, mb, cost);
+        if (grad1) hipLaunchKernelGGL(emd_cost_grad1_kernel, dim3(nb, b), dim3(kThreads), 0, stream, c, partials, grad1);
+        // (the second sweep's partials are unused: cost was already reduced, in stream order, by the finish kernel)
+    } else {
+        hipLaunchKernelGGL(emd_cost_grad1_kernel, dim3(nb, b), dim3(kThreads), 0, stream, c, partials, grad1);
+        hipLaunchKernelGGL(emd_cost_finish_kernel, dim3(b), dim3(256), 0, stream, partials, nb, cost);
+    }
     HP_RETURN_LAST_ERROR();
 }
 
@@ -520,6 +542,6 @@ HP_API int hp_emd_backward(int b, int n, int m, const float* xyz1, const float* 
     HP_CHECK_ARG(ws && grad2 && b <= 65535);
     const WsLayout L = ws_layout(n, m);
     Ctx c{n, m, L.NP, L.MP, xyz1, xyz2, nullptr, const_cast<float*>(ws), L.plp, L.prp, L.rr, L.flp, L.frp, L.per_cloud};
-    hipLaunchKernelGGL(emd_grad2_kernel, dim3((m + kThreads - 1) / kThreads, b), dim3(kThreads), 0, stream, c, grad2);
+    hipLaunchKernelGGL(emd_grad2_kernel<false>, dim3((m + kThreads - 1) / kThreads, b), dim3(kThreads), 0, stream, c, grad2, nullptr);
     HP_RETURN_LAST_ERROR();
 }

@@ -27,26 +27,20 @@ class MatchCostFunction(Function):
         temp = torch.empty((b, (n + m) * 2), **f32)
         ws = torch.empty((max(1, lib.hp_approxmatch_workspace_floats(b, n, m)),), **f32)
         lib.hp_emd_partials_floats.restype = ctypes.c_long
-        part = torch.empty((max(1, lib.hp_emd_partials_floats(b, n)),), **f32)
+        part = torch.empty((max(1, lib.hp_emd_partials_floats(b, n, m)),), **f32)
         cost = torch.empty((b,), **f32)
+        # gradients are by-products of the sweeps that produce the cost: take the ones autograd will ask for now
         grada = torch.empty((b, n, 3), **f32) if ctx.needs_input_grad[0] else None
-        call("hp_emd_forward", b, n, m, seta, setb, temp, ws, part, cost, grada, current_stream(dev))
-        ctx.save_for_backward(seta, setb, ws)
-        ctx.grada = grada
+        gradb = torch.empty((b, m, 3), **f32) if ctx.needs_input_grad[1] else None
+        call("hp_emd_forward", b, n, m, seta, setb, temp, ws, part, cost, grada, gradb, current_stream(dev))
+        ctx.grada, ctx.gradb = grada, gradb
         return cost
 
     @staticmethod
     def backward(ctx, grad_output):
-        seta, setb, ws = ctx.saved_tensors
-        b, n, m = seta.size(0), seta.size(1), setb.size(1)
         grad_output_expand = grad_output.unsqueeze(1).unsqueeze(2)
-        grada = gradb = None
-        if ctx.needs_input_grad[0]:
-            grada = ctx.grada * grad_output_expand
-        if ctx.needs_input_grad[1]:
-            gradb = torch.empty((b, m, 3), dtype=torch.float32, device=seta.device)
-            call("hp_emd_backward", b, n, m, seta, setb, ws, gradb, current_stream(seta.device))
-            gradb = gradb * grad_output_expand
+        grada = ctx.grada * grad_output_expand if ctx.grada is not None else None
+        gradb = ctx.gradb * grad_output_expand if ctx.gradb is not None else None
         return grada, gradb
 
 

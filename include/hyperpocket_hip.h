@@ -47,12 +47,13 @@ int hp_approxmatch(int b, int n, int m, const float* xyz1, const float* xyz2, fl
                    hpStream_t stream);
 
 /* Match-free EMD (what match_cost.py:9-46 computes through ApproxMatch + MatchCost + MatchCostGrad, without ever
- * writing the (b,m,n) match tensor): cost (b,) and grad1 = d cost/d xyz1 in one sweep; hp_emd_backward gives
- * grad2 = d cost/d xyz2 from the packed records hp_emd_forward left in `ws` (hp_approxmatch_workspace_floats).
+ * writing the (b,m,n) match tensor): cost (b,) plus whichever of grad1 = d cost/d xyz1, grad2 = d cost/d xyz2 the
+ * caller asks for (the cost rides on one of those sweeps); hp_emd_backward computes grad2 later from the packed
+ * records hp_emd_forward left in `ws` (hp_approxmatch_workspace_floats).
  * partials: hp_emd_partials_floats floats.  temp as in hp_approxmatch. */
-long hp_emd_partials_floats(int b, int n);
+long hp_emd_partials_floats(int b, int n, int m);
 int hp_emd_forward(int b, int n, int m, const float* xyz1, const float* xyz2, float* temp, float* ws, float* partials,
-                   float* cost, float* grad1 /* or NULL */, hpStream_t stream);
+                   float* cost, float* grad1 /* or NULL */, float* grad2 /* or NULL */, hpStream_t stream);
 int hp_emd_backward(int b, int n, int m, const float* xyz1, const float* xyz2, const float* ws, float* grad2,
                     hpStream_t stream);
 
