@@ -370,13 +370,14 @@ int launch_cfg(KParams& p, int batch, hipStream_t stream) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     dim3 grid(p.tiles_m * p.tiles_n, batch * p.ksplit), block(WGM * WGN * 64);
-    const bool a_kc = p.sAk == 1, b_kc = p.sBk == 1;
-    // every split's k-range must be whole k-tiles, K-contiguous operands need 16-byte loads
-    const bool fast = p.K % BK == 0 && (!a_kc || p.vecA) && (!b_kc || p.vecB) && p.K > 0;
+    // fast loaders need whole k-tiles; a K-contiguous operand that is not 16-byte loadable (e.g. the per-cloud weight
+    // slices of theta, row stride 19011) takes the strided-scalar loader with s_k = 1 instead of the generic path
+    const bool a_vk = p.sAk == 1 && p.vecA, b_vk = p.sBk == 1 && p.vecB;
+    const bool fast = p.K % BK == 0 && p.K > 0;
     if (!fast) hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, -1>), grid, block, 0, stream, p);
-    else if (a_kc && b_kc) hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, 3>), grid, block, 0, stream, p);
-    else if (a_kc) hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, 1>), grid, block, 0, stream, p);
-    else if (b_kc) hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, 2>), grid, block, 0, stream, p);
+    else if (a_vk && b_vk) hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, 3>), grid, block, 0, stream, p);
+    else if (a_vk) hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, 1>), grid, block, 0, stream, p);
+    else if (b_vk) hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, 2>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, 0>), grid, block, 0, stream, p);
     return (int)hipGetLastError();
 }
