@@ -83,7 +83,7 @@ __device__ __forceinline__ float4 ld4_fast(const float* __restrict__ p, long s_k
 // them), the k-range is a multiple of BK and K-contiguous operands are 16-byte aligned (checked on the host).
 // The generic loaders' divergent-branch scaffolding costs ~30 % of the MFMA rate (tools/exp_gemm.py).
 template <int BM, int BN, int WGM, int WGN, int BK, int MODE>
-__global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const KParams p) {
+__global__ __launch_bounds__(WGM* WGN * 64, (BM == 128 && BN == 128) ? 4 : 1) void gemm_kernel(const KParams p) {
     constexpr int NT = WGM * WGN * 64;
     constexpr int LDK = BK + 4, KQ = BK / 4;   // KQ float4 groups per staged row
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
