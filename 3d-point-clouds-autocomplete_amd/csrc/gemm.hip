@@ -53,6 +53,9 @@ struct KParams {
     float* cmax;
     int* cidx;
     int group_rows;
+    float* rsum;
+    long sRsumz;
+    long ws_rsum_off;   // offset (floats) of the row-sum partials inside ws when ksplit > 1
 };
 
 __device__ __forceinline__ float4 ld4(const float* __restrict__ base, long rowoff, int k, long s_k, bool row_ok, int kend, bool vec) {
@@ -135,6 +138,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (BM == 128 && BN == 128) ? 4 : 1) vo
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    float rowsum = 0.f;
     float4 ra[NA], rb[NB];
     // fast path: per-thread base pointers (row clamped into range), advanced by BK*s_k per k-tile
     const float* pa[NA];
@@ -187,6 +191,13 @@ __global__ __launch_bounds__(WGM* WGN * 64, (BM == 128 && BN == 128) ? 4 : 1) vo
             if (BN * KQ % NT == 0 || tid + e * NT < BN * KQ) *reinterpret_cast<float4*>(&Bs[b_row[e] * LDK + b_kq[e] * 4]) = rb[e];
         __syncthreads();
         if (k0 + BK < kend) fetch(k0 + BK);  // next tile's global loads fly under this tile's MFMAs
+        if ((p.flags & HP_GEMM_ROWSUM) && tile_n == 0 && tid < BM) {   // bias gradient: row sums of the staged A tile
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(&As[tid * LDK + q * 4]);
+                rowsum += (v.x + v.y) + (v.z + v.w);
+            }
+        }
 #pragma unroll
         for (int t = 0; t < BK / 8; ++t) {
             float4 a[TM], b[TN];
@@ -212,6 +223,10 @@ __global__ __launch_bounds__(WGM* WGN * 64, (BM == 128 && BN == 128) ? 4 : 1) vo
         __syncthreads();
     }
 
+    if ((p.flags & HP_GEMM_ROWSUM) && tile_n == 0 && tid < BM && row0 + tid < p.M) {
+        if (p.ksplit > 1) p.ws[p.ws_rsum_off + (long)blockIdx.y * p.M + row0 + tid] = rowsum;
+        else p.rsum[(long)z * p.sRsumz + row0 + tid] = rowsum;
+    }
     // epilogue.  C/D map of the 32x32 f32 tile: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
     if (p.flags & HP_GEMM_COLMAX) {
         // fused max-pool over this tile's rows (model/encoder.py:45): first row attaining the max wins
@@ -311,6 +326,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams p) {
         if (mask) v = (mask[(long)row * p.ldmask + col] > 0.f) ? v : 0.f;
         C[(long)row * p.ldc + col] = v;
     }
+    if ((p.flags & HP_GEMM_ROWSUM) && blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < p.M; i += 256) {
+            const float* w = p.ws + p.ws_rsum_off + (long)z * p.ksplit * p.M + i;
+            float s = 0.f;
+            for (int q = 0; q < p.ksplit; ++q) s += w[(long)q * p.M];
+            p.rsum[(long)z * p.sRsumz + i] = s;
+        }
+    }
 }
 
 // Column sums (bias gradients): out[z][j] = sum_i X[z](i,j).
@@ -401,7 +424,7 @@ int choose_cfg(const HpGemmDesc* d, int ksplit) {
 
 HP_API long hp_gemm_workspace_floats(const HpGemmDesc* d) {
     if (!d || d->ksplit <= 1) return 0;
-    return (long)d->batch * d->ksplit * d->M * d->N;
+    return (long)d->batch * d->ksplit * d->M * d->N + ((d->flags & HP_GEMM_ROWSUM) ? (long)d->batch * d->ksplit * d->M : 0);
 }
 
 // rows per output tile hp_gemm_f32 will use for this problem (HP_GEMM_COLMAX partial layout)
@@ -423,12 +446,15 @@ HP_API int hp_gemm_f32(const HpGemmDesc* d, hipStream_t stream) {
     HP_CHECK_ARG(!(d->flags & HP_GEMM_BIAS) || d->bias);
     HP_CHECK_ARG(!(d->flags & HP_GEMM_MASK) || d->mask);
     HP_CHECK_ARG(!(d->flags & HP_GEMM_ADD) || d->add);
+    HP_CHECK_ARG(!(d->flags & HP_GEMM_ROWSUM) || d->rsum);
     HP_CHECK_ARG(d->batch * (long)(d->ksplit > 1 ? d->ksplit : 1) <= 65535);
     KParams p;
     p.A = d->A; p.B = d->B; p.C = d->C; p.bias = d->bias; p.mask = d->mask; p.add = d->add; p.ws = d->ws;
     p.sAz = d->sAz; p.sBz = d->sBz; p.sCz = d->sCz; p.sBiasz = d->sBiasz; p.sMaskz = d->sMaskz; p.sAddz = d->sAddz;
     p.ldadd = d->ldadd;
     p.cmax = d->cmax; p.cidx = d->cidx; p.group_rows = d->group_rows;
+    p.rsum = d->rsum; p.sRsumz = d->sRsumz;
+    p.ws_rsum_off = (long)d->batch * (d->ksplit > 1 ? d->ksplit : 1) * d->M * d->N;
     p.sAi = d->sAi; p.sAk = d->sAk; p.sBk = d->sBk; p.sBj = d->sBj;
     p.ldc = d->ldc; p.ldmask = d->ldmask; p.M = d->M; p.N = d->N; p.K = d->K; p.flags = d->flags;
     p.ksplit = d->ksplit > 1 ? d->ksplit : 1;

@@ -5,6 +5,7 @@
 #define HP_GEMM_RELU 2 /* max(., 0)                                   */
 #define HP_GEMM_MASK 4 /* * (mask(i,j) > 0)  — ReLU backward, fused   */
 #define HP_GEMM_ADD 8  /* + add(i,j)  (before ReLU / mask)             */
+#define HP_GEMM_ROWSUM 32 /* also rsum(i) = sum_k A(i,k): the bias gradient rides on the dW = dY^T X contraction */
 #define HP_GEMM_COLMAX 16 /* do not store C: per row-tile column max (+bias) and its row -> cmax/cidx (fused max-pool) */
 
 typedef struct HpGemmDesc {
@@ -26,4 +27,7 @@ typedef struct HpGemmDesc {
     float* cmax;
     int* cidx;
     int group_rows;
+    /* HP_GEMM_ROWSUM: rsum(i) at rsum + z*sRsumz + i ; with split-K the workspace needs batch*ksplit*M more floats */
+    float* rsum;
+    long sRsumz;
 } HpGemmDesc;

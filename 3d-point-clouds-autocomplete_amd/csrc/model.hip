@@ -84,9 +84,9 @@ struct Op {
         d.ws = splitws;
         return hp_gemm_f32(&d, s);
     }
-    // dW(NxK) = dY(MxN, ldy)^T X(MxK, ldx)     (contraction over the M rows)
+    // dW(NxK) = dY(MxN, ldy)^T X(MxK, ldx)     (contraction over the M rows);  db(N) = column sums of dY ride along
     int lin_dw(const float* dY, long sdYz, int ldy, const float* X, long sXz, int ldx, float* dW, long sdWz, int M, int N,
-               int K, int batch) const {
+               int K, int batch, float* db = nullptr, long sdbz = 0) const {
         HpGemmDesc d{};
         d.A = dY; d.sAz = sdYz; d.sAi = 1; d.sAk = ldy;
         d.B = X; d.sBz = sXz; d.sBk = ldx; d.sBj = 1;
@@ -94,6 +94,12 @@ struct Op {
         d.M = N; d.N = K; d.K = M; d.batch = batch;
         d.ksplit = pick_ksplit(N, K, M, batch);
         d.ws = splitws;
+        if (db) {
+            d.flags |= HP_GEMM_ROWSUM;
+            d.rsum = db;
+            d.sRsumz = sdbz;
+            while (d.ksplit > 1 && (long)batch * d.ksplit * ((long)N * K + N) > kSplitWs) --d.ksplit;
+        }
         return hp_gemm_f32(&d, s);
     }
     int colsum(const float* X, long sXz, int ldx, int M, int N, int batch, float* out, long sOz) const {
@@ -178,10 +184,16 @@ __global__ __launch_bounds__(256) void gather_rows3_kernel(const float* __restri
 // Layer-5 backward on the critical rows (one-hot upstream):
 //   dW5[c,k]       = sum_b dg[b,c] * h4c[(b,c),k]
 //   d4[(b,c),k]    = dg[b,c] * W5[c,k] * (h4c[(b,c),k] > 0)
+//   db5[c]         = sum_b dg[b,c]
 __global__ __launch_bounds__(256) void enc_l5_bwd_kernel(int B, int C, int K, const float* __restrict__ dg,
                                                          const float* __restrict__ W5, const float* __restrict__ h4c,
-                                                         float* __restrict__ dW5, float* __restrict__ d4) {
+                                                         float* __restrict__ dW5, float* __restrict__ d4, float* __restrict__ db5) {
     const int c = blockIdx.x;
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dg[(long)b * C + c];
+        db5[c] = s;
+    }
     for (int k = threadIdx.x; k < K; k += 256) {
         const float w = W5[(long)c * K + k];
         float s = 0.f;
@@ -316,17 +328,14 @@ HP_API int hp_encoder_backward(int B, int Np, const float* x, const HpEncoderWei
         hipLaunchKernelGGL(vae_head_bwd_kernel, dim3((int)cdiv(n, 256)), dim3(256), 0, stream, n, eps, lv, grad_out, grad_mu,
                            grad_explv, dmu, dlv);
         dmu_p = dmu;
-        TRY(op.lin_dw(dlv, 0, out_size, f, 0, 512, gr->std_w, 0, B, out_size, 512, 1));
-        TRY(op.colsum(dlv, 0, out_size, B, out_size, 1, gr->std_b, 0));
+        TRY(op.lin_dw(dlv, 0, out_size, f, 0, 512, gr->std_w, 0, B, out_size, 512, 1, gr->std_b));
         TRY(op.lin_dx(dlv, 0, out_size, w->std_w, 0, tmp, 0, 512, B, out_size, 512, 1, nullptr, 0, 0, nullptr, 0));
     } else {
         dmu_p = grad_out;
     }
-    TRY(op.lin_dw(dmu_p, 0, out_size, f, 0, 512, gr->mu_w, 0, B, out_size, 512, 1));
-    TRY(op.colsum(dmu_p, 0, out_size, B, out_size, 1, gr->mu_b, 0));
+    TRY(op.lin_dw(dmu_p, 0, out_size, f, 0, 512, gr->mu_w, 0, B, out_size, 512, 1, gr->mu_b));
     TRY(op.lin_dx(dmu_p, 0, out_size, w->mu_w, 0, dfc, 0, 512, B, out_size, 512, 1, f, 0, 512, is_vae ? tmp : nullptr, 512));
-    TRY(op.lin_dw(dfc, 0, 512, g, 0, 512, gr->fc_w, 0, B, 512, 512, 1));
-    TRY(op.colsum(dfc, 0, 512, B, 512, 1, gr->fc_b, 0));
+    TRY(op.lin_dw(dfc, 0, 512, g, 0, 512, gr->fc_w, 0, B, 512, 512, 1, gr->fc_b));
     TRY(op.lin_dx(dfc, 0, 512, w->fc_w, 0, dg, 0, 512, B, 512, 512, 1, nullptr, 0, 0, nullptr, 0));
 
     // ---- conv stack on the B*512 critical rows
@@ -338,12 +347,11 @@ HP_API int hp_encoder_backward(int B, int Np, const float* x, const HpEncoderWei
         in = hc[l];
     }
     hipLaunchKernelGGL(enc_l5_bwd_kernel, dim3(512), dim3(256), 0, stream, B, 512, 512, dg, w->conv_w[4], hc[4], gr->conv_w[4],
-                       dl[4]);
-    TRY(op.colsum(dg, 0, 512, B, 512, 1, gr->conv_b[4], 0));
+                       dl[4], gr->conv_b[4]);
     for (int l = 4; l >= 1; --l) {
         const float* below = l > 1 ? hc[l - 1] : xc;
-        TRY(op.lin_dw(dl[l], 0, kEnc[l], below, 0, kEnc[l - 1], gr->conv_w[l - 1], 0, (int)Rc, kEnc[l], kEnc[l - 1], 1));
-        TRY(op.colsum(dl[l], 0, kEnc[l], (int)Rc, kEnc[l], 1, gr->conv_b[l - 1], 0));
+        TRY(op.lin_dw(dl[l], 0, kEnc[l], below, 0, kEnc[l - 1], gr->conv_w[l - 1], 0, (int)Rc, kEnc[l], kEnc[l - 1], 1,
+                      gr->conv_b[l - 1]));
         if (l > 1)
             TRY(op.lin_dx(dl[l], 0, kEnc[l], w->conv_w[l - 1], 0, dl[l - 1], 0, kEnc[l - 1], (int)Rc, kEnc[l], kEnc[l - 1], 1,
                           hc[l - 1], 0, kEnc[l - 1], nullptr, 0));
@@ -405,8 +413,7 @@ HP_API int hp_hypernet_backward(int B, int in_size, const float* latent, const H
     int off = 0;
     for (int hd = 0; hd < w->n_heads; ++hd) {
         const int nh = w->head_out[hd];
-        TRY(op.lin_dw(grad_theta + off, 0, theta_ld, act[4], 0, 2048, gr->head_w[hd], 0, B, nh, 2048, 1));
-        TRY(op.colsum(grad_theta + off, 0, theta_ld, B, nh, 1, gr->head_b[hd], 0));
+        TRY(op.lin_dw(grad_theta + off, 0, theta_ld, act[4], 0, 2048, gr->head_w[hd], 0, B, nh, 2048, 1, gr->head_b[hd]));
         TRY(op.lin_dx(grad_theta + off, 0, theta_ld, w->head_w[hd], 0, dt[4], 0, 2048, B, nh, 2048, 1, nullptr, 0, 0,
                       hd ? dt[4] : nullptr, 2048));
         off += nh;
@@ -415,8 +422,7 @@ HP_API int hp_hypernet_backward(int B, int in_size, const float* latent, const H
     for (int l = 4; l >= 0; --l) {
         const float* below = l ? act[l - 1] : latent;
         const int kin = l ? kTrunk[l - 1] : in_size;
-        TRY(op.lin_dw(dt[l], 0, kTrunk[l], below, 0, kin, gr->trunk_w[l], 0, B, kTrunk[l], kin, 1));
-        TRY(op.colsum(dt[l], 0, kTrunk[l], B, kTrunk[l], 1, gr->trunk_b[l], 0));
+        TRY(op.lin_dw(dt[l], 0, kTrunk[l], below, 0, kin, gr->trunk_w[l], 0, B, kTrunk[l], kin, 1, gr->trunk_b[l]));
         if (l > 0)
             TRY(op.lin_dx(dt[l], 0, kTrunk[l], w->trunk_w[l], 0, dt[l - 1], 0, kin, B, kTrunk[l], kin, 1, act[l - 1], 0, kin,
                           nullptr, 0));
@@ -516,8 +522,8 @@ HP_API int hp_target_backward(int B, int N, int n_hidden, const int* channels, c
     for (int l = L.nl - 1; l >= 0; --l) {
         const float* below = l ? act[l - 1] : pts;
         const int cin = L.cin[l], cout = L.cout[l];
-        TRY(op.lin_dw(d, (long)N * cout, cout, below, (long)N * cin, cin, grad_theta + L.woff[l], theta_ld, N, cout, cin, B));
-        TRY(op.colsum(d, (long)N * cout, cout, N, cout, B, grad_theta + L.boff[l], theta_ld));
+        TRY(op.lin_dw(d, (long)N * cout, cout, below, (long)N * cin, cin, grad_theta + L.woff[l], theta_ld, N, cout, cin, B,
+                      grad_theta + L.boff[l], theta_ld));
         if (l > 0) {
             TRY(op.lin_dx(d, (long)N * cout, cout, theta + L.woff[l], theta_ld, dl[l - 1], (long)N * cin, cin, N, cout, cin, B,
                           act[l - 1], (long)N * cin, cin, nullptr, 0));

@@ -121,6 +121,7 @@ __global__ __launch_bounds__(kThreads) void nn_grad_direct_kernel(int b, int n, 
         const int j2 = idx1[t];
         const float* p = xyz1 + t * 3;
         const float* q = xyz2 + (i * m + j2) * 3;
+        if (!g1) return;
         const float g = gd1[t * gd1_stride] * 2;
         g1[t * 3 + 0] = g * (p[0] - q[0]);
         g1[t * 3 + 1] = g * (p[1] - q[1]);
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(kThreads) void nn_grad_direct_kernel(int b, int n, 
         const int j2 = idx2[u];
         const float* p = xyz2 + u * 3;
         const float* q = xyz1 + (i * n + j2) * 3;
+        if (!g2) return;
         const float g = gd2[u * gd2_stride] * 2;
         g2[u * 3 + 0] = g * (p[0] - q[0]);
         g2[u * 3 + 1] = g * (p[1] - q[1]);
@@ -152,6 +154,7 @@ __global__ __launch_bounds__(kThreads) void nn_grad_scatter_kernel(int b, int n,
         const int j2 = idx1[t];
         const float* p = xyz1 + t * 3;
         const float* q = xyz2 + (i * m + j2) * 3;
+        if (!g2) return;
         const float g = gd1[t * gd1_stride] * 2;
         float* o = g2 + (i * m + j2) * 3;
         atomicAdd(o + 0, -(g * (p[0] - q[0])));
@@ -163,6 +166,7 @@ __global__ __launch_bounds__(kThreads) void nn_grad_scatter_kernel(int b, int n,
         const int j2 = idx2[u];
         const float* p = xyz2 + u * 3;
         const float* q = xyz1 + (i * n + j2) * 3;
+        if (!g1) return;
         const float g = gd2[u * gd2_stride] * 2;
         float* o = g1 + (i * n + j2) * 3;
         atomicAdd(o + 0, -(g * (p[0] - q[0])));
@@ -357,10 +361,11 @@ HP_API int hp_chamfer_forward(int b, int n, const float* preds, int m, const flo
 }
 
 // Fused Chamfer backward: d loss / d preds and d loss / d gts for upstream scalar *grad_loss (device).
+// Either output may be NULL (training only needs the gradient of the reconstruction).
 HP_API int hp_chamfer_backward(int b, int n, const float* preds, int m, const float* gts, const int* idx1,
                                const int* idx2, const float* grad_loss, float* grad_preds, float* grad_gts,
                                hipStream_t stream) {
-    HP_CHECK_ARG(b > 0 && n > 0 && m > 0);
+    HP_CHECK_ARG(b > 0 && n > 0 && m > 0 && (grad_preds || grad_gts));
     const size_t tot = (size_t)b * n + (size_t)b * m;
     const int blocks = (int)((tot + kThreads - 1) / kThreads);
     hipLaunchKernelGGL(nn_grad_direct_kernel, dim3(blocks), dim3(kThreads), 0, stream, b, n, preds, m, gts, grad_loss, 0, idx1,

@@ -37,8 +37,8 @@ class _ChamferFunction(Function):
         preds_c, gts_c, idx1, idx2 = ctx.saved_tensors
         b, n, m = preds_c.size(0), preds_c.size(1), gts_c.size(1)
         g = grad_loss.to(torch.float32).contiguous()
-        grad_preds = torch.empty_like(preds_c)
-        grad_gts = torch.empty_like(gts_c)
+        grad_preds = torch.empty_like(preds_c) if ctx.needs_input_grad[0] else None
+        grad_gts = torch.empty_like(gts_c) if ctx.needs_input_grad[1] else None
         call("hp_chamfer_backward", b, n, preds_c, m, gts_c, idx1, idx2, g, grad_preds, grad_gts,
              current_stream(preds_c.device))
         return grad_preds, grad_gts

@@ -256,7 +256,7 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
          float(grad_scale), current_stream(p.device))
 
 
-def gemm(A, B, bias=None, relu=False, trans_a=False, trans_b=True, mask=None, add=None, ksplit=1):
+def gemm(A, B, bias=None, relu=False, trans_a=False, trans_b=True, mask=None, add=None, ksplit=1, rowsum=False):
     """Thin test hook over hp_gemm_f32 for 2-D / 3-D (batched) fp32 tensors:
     C = epi(op(A) @ op(B)); trans_b=True means B is stored (N, K) like an nn.Linear weight."""
     class _Desc(ctypes.Structure):
@@ -266,7 +266,7 @@ def gemm(A, B, bias=None, relu=False, trans_a=False, trans_b=True, mask=None, ad
                     ("sAi", c_long), ("sAk", c_long), ("sBk", c_long), ("sBj", c_long),
                     ("ldc", c_int), ("ldmask", c_int), ("ldadd", c_int),
                     ("M", c_int), ("N", c_int), ("K", c_int), ("batch", c_int), ("ksplit", c_int), ("flags", c_int),
-                    ("cmax", c_void_p), ("cidx", c_void_p), ("group_rows", c_int)]
+                    ("cmax", c_void_p), ("cidx", c_void_p), ("group_rows", c_int), ("rsum", c_void_p), ("sRsumz", c_long)]
     batched = A.dim() == 3
     A3 = A if batched else A.unsqueeze(0)
     B3 = B if B.dim() == 3 else B.unsqueeze(0)
@@ -301,10 +301,18 @@ def gemm(A, B, bias=None, relu=False, trans_a=False, trans_b=True, mask=None, ad
         check_input(add3, "add")
         d.add, d.sAddz, d.ldadd = add3.data_ptr(), M * N, N
         flags |= 8
+    rs = None
+    if rowsum:
+        rs = torch.empty((batch, M), dtype=torch.float32, device=A.device)
+        d.rsum, d.sRsumz = rs.data_ptr(), M
+        flags |= 32
     d.flags = flags
     ws = None
     if ksplit > 1:
-        ws = torch.empty((batch * ksplit * M * N,), dtype=torch.float32, device=A.device)
+        ws = torch.empty((batch * ksplit * (M * N + M),), dtype=torch.float32, device=A.device)
         d.ws = ws.data_ptr()
     call("hp_gemm_f32", ctypes.byref(d), current_stream(A.device))
-    return C if batched else C[0]
+    out = C if batched else C[0]
+    if rowsum:
+        return out, (rs if batched else rs[0])
+    return out

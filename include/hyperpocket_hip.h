@@ -88,6 +88,7 @@ int hp_chamfer_backward(int b, int n, const float* preds, int m, const float* gt
 #define HP_GEMM_RELU 2
 #define HP_GEMM_MASK 4
 #define HP_GEMM_ADD 8
+#define HP_GEMM_ROWSUM 32 /* also rsum(i) = sum_k A(i,k): the bias gradient rides on the dW = dY^T X contraction */
 #define HP_GEMM_COLMAX 16 /* do not store C: per row-tile column max (+bias) and its row -> cmax/cidx (fused max-pool) */
 
 typedef struct HpGemmDesc {
@@ -109,6 +110,9 @@ typedef struct HpGemmDesc {
     float* cmax;
     int* cidx;
     int group_rows;
+    /* HP_GEMM_ROWSUM: rsum(i) at rsum + z*sRsumz + i ; with split-K the workspace needs batch*ksplit*M more floats */
+    float* rsum;
+    long sRsumz;
 } HpGemmDesc;
 
 long hp_gemm_workspace_floats(const HpGemmDesc* d);

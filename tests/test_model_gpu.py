@@ -91,6 +91,15 @@ def test_gemm_epilogues_and_splitk_and_batch():
     assert torch.equal(g1, g2)
     grad_close(g1, want, tol=1e-5)
     grad_close(gemm(dY.cuda(), X.cuda(), trans_a=True, trans_b=False), want, tol=1e-5)
+    # bias gradient riding on the dW contraction (row sums of the transposed operand), with and without split-K, batched
+    for ks in (1, 7):
+        dW, db = gemm(dY.cuda(), X.cuda(), trans_a=True, trans_b=False, ksplit=ks, rowsum=True)
+        grad_close(dW, want, tol=1e-5)
+        grad_close(db, dY.double().sum(0), tol=1e-5)
+    dYb, Xb = torch.randn(3, 1000, 40, generator=g), torch.randn(3, 1000, 130, generator=g)
+    dW, db = gemm(dYb.cuda(), Xb.cuda(), trans_a=True, trans_b=False, rowsum=True)
+    grad_close(dW, torch.bmm(dYb.double().transpose(1, 2), Xb.double()), tol=1e-5)
+    grad_close(db, dYb.double().sum(1), tol=1e-5)
 
 
 # ----------------------------------------------------------------------------- components vs oracle
