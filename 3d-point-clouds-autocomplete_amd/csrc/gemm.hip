@@ -152,7 +152,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (BM == 128 && BN == 128) ? 4 : 1) vo
             pb[e] = B + (long)min(col0 + b_row[e], p.N - 1) * p.sBj + (long)(kbeg + b_kq[e] * 4) * p.sBk;
     }
     auto fetch = [&](int k0) {
-        if (MODE >= 0) {
+        if (MODE >= 0 && k0 + BK <= kend) {   // whole k-tile: branch-free loaders; a K tail falls through to the generic ones
 #pragma unroll
             for (int e = 0; e < NA; ++e)
                 if (BM * KQ % NT == 0 || tid + e * NT < BM * KQ) {
@@ -393,12 +393,11 @@ int launch_cfg(KParams& p, int batch, hipStream_t stream) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     dim3 grid(p.tiles_m * p.tiles_n, batch * p.ksplit), block(WGM * WGN * 64);
-    // fast loaders need whole k-tiles; a K-contiguous operand that is not 16-byte loadable (e.g. the per-cloud weight
-    // slices of theta, row stride 19011) takes the strided-scalar loader with s_k = 1 instead of the generic path
+    // MODE bit = "K-contiguous AND 16-byte loadable"; a K-contiguous operand that is not (e.g. the per-cloud weight
+    // slices of theta, row stride 19011) takes the strided-scalar loader with s_k = 1.  Whole k-tiles use the
+    // branch-free loaders, a K tail (or K < BK) the predicated ones inside the same kernel.
     const bool a_vk = p.sAk == 1 && p.vecA, b_vk = p.sBk == 1 && p.vecB;
-    const bool fast = p.K % BK == 0 && p.K > 0;
-    if (!fast) hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, -1>), grid, block, 0, stream, p);
-    else if (a_vk && b_vk) hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, 3>), grid, block, 0, stream, p);
+    if (a_vk && b_vk) hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, 3>), grid, block, 0, stream, p);
     else if (a_vk) hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, 1>), grid, block, 0, stream, p);
     else if (b_vk) hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, 2>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, 0>), grid, block, 0, stream, p);
