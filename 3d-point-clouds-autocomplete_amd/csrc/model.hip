@@ -43,8 +43,9 @@ inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 // split the contraction when the output alone cannot fill 256 CUs
 int pick_ksplit(int outM, int outN, int kc, int batch) {
     const long tiles = cdiv(outM, 64) * cdiv(outN, 64) * batch;
-    if (tiles >= 256 || kc < 256) return 1;
-    long ks = std::min<long>(cdiv(512, tiles), kc / 128);
+    if (tiles >= 512 || kc < 256) return 1;
+    long ks = tiles >= 256 ? std::min<long>(cdiv(768, tiles), kc / 512)      // long skinny K loops (M = B heads GEMM)
+                           : std::min<long>(cdiv(512, tiles), kc / 128);
     ks = std::max<long>(1, std::min<long>(ks, 64));
     while (ks > 1 && (long)outM * outN * batch * ks > kSplitWs) --ks;
     return (int)ks;
@@ -362,6 +363,15 @@ HP_API int hp_encoder_backward(int B, int Np, const float* x, const HpEncoderWei
 // =================================================================================================
 // Hypernetwork
 // =================================================================================================
+namespace {
+template <typename P>
+bool heads_contiguous(P const* hw, P const* hb, const int* out, int n) {
+    for (int h = 0; h + 1 < n; ++h)
+        if (hw[h + 1] != hw[h] + (long)out[h] * 2048 || hb[h + 1] != hb[h] + out[h]) return false;
+    return n > 0;
+}
+}  // namespace
+
 // saved trunk activations + the split-K slab area the skinny (M = B) forward GEMMs use
 HP_API long hp_hypernet_saved_floats(int B) { return (long)B * (64 + 128 + 512 + 1024 + 2048) + kSplitWs + 64; }
 HP_API long hp_hypernet_backward_workspace_floats(int B) { return (long)B * (64 + 128 + 512 + 1024 + 2048) + kSplitWs + 64; }
@@ -380,13 +390,20 @@ HP_API int hp_hypernet_forward(int B, int in_size, const float* latent, const Hp
         kin = kTrunk[l];
         tl += (long)B * kTrunk[l];
     }
-    int off = 0;
-    for (int hd = 0; hd < w->n_heads; ++hd) {
-        TRY(op.lin_fwd(in, 0, 2048, w->head_w[hd], 0, w->head_b[hd], 0, theta + off, 0, theta_ld, B, w->head_out[hd], 2048, 1,
-                       false));
-        off += w->head_out[hd];
+    int total = 0;
+    for (int hd = 0; hd < w->n_heads; ++hd) total += w->head_out[hd];
+    HP_CHECK_ARG(total <= theta_ld);
+    if (heads_contiguous(w->head_w, w->head_b, w->head_out, w->n_heads)) {
+        // the heads' weights form one (total x 2048) matrix (FlatParameters lays them out back to back): one GEMM
+        TRY(op.lin_fwd(in, 0, 2048, w->head_w[0], 0, w->head_b[0], 0, theta, 0, theta_ld, B, total, 2048, 1, false));
+    } else {
+        int off = 0;
+        for (int hd = 0; hd < w->n_heads; ++hd) {
+            TRY(op.lin_fwd(in, 0, 2048, w->head_w[hd], 0, w->head_b[hd], 0, theta + off, 0, theta_ld, B, w->head_out[hd], 2048,
+                           1, false));
+            off += w->head_out[hd];
+        }
     }
-    HP_CHECK_ARG(off <= theta_ld);
     HP_RETURN_LAST_ERROR();
 }
 
@@ -410,8 +427,15 @@ HP_API int hp_hypernet_backward(int B, int in_size, const float* latent, const H
     }
     Op op{stream, p};
     // heads: dW_h = dtheta_h^T t5 ; db_h = colsum ; dt5 = sum_h dtheta_h W_h
-    int off = 0;
-    for (int hd = 0; hd < w->n_heads; ++hd) {
+    int off = 0, total = 0;
+    for (int hd = 0; hd < w->n_heads; ++hd) total += w->head_out[hd];
+    const bool fused = heads_contiguous(w->head_w, w->head_b, w->head_out, w->n_heads) &&
+                       heads_contiguous(gr->head_w, gr->head_b, w->head_out, w->n_heads);
+    if (fused) {
+        TRY(op.lin_dw(grad_theta, 0, theta_ld, act[4], 0, 2048, gr->head_w[0], 0, B, total, 2048, 1, gr->head_b[0]));
+        TRY(op.lin_dx(grad_theta, 0, theta_ld, w->head_w[0], 0, dt[4], 0, 2048, B, total, 2048, 1, nullptr, 0, 0, nullptr, 2048));
+    }
+    for (int hd = 0; hd < w->n_heads && !fused; ++hd) {
         const int nh = w->head_out[hd];
         TRY(op.lin_dw(grad_theta + off, 0, theta_ld, act[4], 0, 2048, gr->head_w[hd], 0, B, nh, 2048, 1, gr->head_b[hd]));
         TRY(op.lin_dx(grad_theta + off, 0, theta_ld, w->head_w[hd], 0, dt[4], 0, 2048, B, nh, 2048, 1, nullptr, 0, 0,

@@ -33,7 +33,10 @@ class FlatParameters:
             if name.startswith("hyper_network"):
                 return 1
             return 2
-        named.sort(key=lambda np_: bucket_of(np_[0]))     # stable: keeps module order inside a bucket
+        # stable sort: module order inside a bucket, except that the heads' weights come first and back to back, then
+        # their biases — the five (n_h x 2048) matrices then form ONE (19011 x 2048) matrix and the hypernetwork's
+        # head GEMMs (forward, dW, dX) run as single launches (csrc/model.hip: heads_contiguous)
+        named.sort(key=lambda np_: (bucket_of(np_[0]), np_[0].endswith(".bias") if bucket_of(np_[0]) == 0 else False))
         self.names = [n for n, _ in named]
         self.params = [p for _, p in named]
         dev = self.params[0].device
