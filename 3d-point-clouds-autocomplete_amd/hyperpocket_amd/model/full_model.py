@@ -66,6 +66,7 @@ class FullModel(nn.Module):
         # 'device': one Philox launch per step (fast path); 'reference': the reference's per-cloud CPU
         # draws from the torch global generator, value for value (utils/points.py)
         self.point_sampler = 'device'
+        self.concurrent_encoders = True   # HyperPocket training: run the two independent encoders on two streams
         self._sampler_seed = None
         self._sampler_calls = 0
 
@@ -123,12 +124,34 @@ class ModelMode(object):
         raise NotImplementedError
 
 
+def _side_stream(model, device):
+    """One extra HIP stream per model: the two encoders of a HyperPocket step are independent, so the VAE encoder runs
+    there while the plain one runs on the caller's stream (their many small head kernels then hide under the other's
+    wide GEMMs, forward and — autograd replays each node on its forward stream — backward)."""
+    streams = model.__dict__.setdefault("_side_streams", {})
+    key = (device.type, device.index)
+    if key not in streams:
+        streams[key] = torch.cuda.Stream(device=device)
+    return streams[key]
+
+
 class HyperPocket(ModelMode):
 
     def get_latent(self, model: FullModel, existing, missing, noise=None, eps=None):
         if model.training:
-            codes, mu, logvar = model.random_encoder(missing, eps)
-            real_mu = model.real_encoder(existing)
+            if model.concurrent_encoders and missing.is_cuda:
+                cur = torch.cuda.current_stream(missing.device)
+                side = _side_stream(model, missing.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    codes, mu, logvar = model.random_encoder(missing, eps)
+                real_mu = model.real_encoder(existing)
+                cur.wait_stream(side)
+                for t in (codes, mu, logvar):
+                    t.record_stream(cur)
+            else:
+                codes, mu, logvar = model.random_encoder(missing, eps)
+                real_mu = model.real_encoder(existing)
             latent = torch.cat([codes, real_mu], 1)
             return latent, mu, logvar
         else:
