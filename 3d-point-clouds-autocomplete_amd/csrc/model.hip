@@ -298,29 +298,69 @@ HP_API int hp_encoder_forward(int B, int Np, const float* x, const HpEncoderWeig
     HP_RETURN_LAST_ERROR();
 }
 
+namespace {
+struct EncBwdWs {
+    float* xc;
+    float* hc[5];
+    float* dl[5];
+    float *dmu, *dlv, *tmp, *dfc, *dg, *split;
+};
+EncBwdWs enc_bwd_layout(float* ws, long B, long out_size) {
+    const long Rc = B * 512;
+    float* p = ws;
+    auto take = [&](long n) { float* r = p; p += (n + 3) / 4 * 4; return r; };
+    EncBwdWs L;
+    L.xc = take(Rc * 3);
+    for (int l = 1; l <= 4; ++l) L.hc[l] = take(Rc * kEnc[l]);
+    for (int l = 1; l <= 4; ++l) L.dl[l] = take(Rc * kEnc[l]);
+    L.dmu = take(B * out_size);
+    L.dlv = take(B * out_size);
+    L.tmp = take(B * 512);
+    L.dfc = take(B * 512);
+    L.dg = take(B * 512);
+    L.split = take(kSplitWs);
+    return L;
+}
+}  // namespace
+
+// The gradient-independent half of the encoder backward: gather the B*512 critical rows (arg-max points) and
+// recompute their activations h1..h4 into `ws` (the hp_encoder_backward workspace).  It needs only the forward's
+// arg-max, so a caller may run it EARLY on another stream, under the rest of the forward / the loss kernels, and
+// pass prepared=1 to hp_encoder_backward.
+HP_API int hp_encoder_backward_prepare(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size,
+                                       const int* argidx, float* ws, hipStream_t stream) {
+    HP_CHECK_ARG(B > 0 && Np > 0 && out_size > 0 && x && w && argidx && ws);
+    const long Rc = (long)B * 512;
+    EncBwdWs L = enc_bwd_layout(ws, B, out_size);
+    Op op{stream, nullptr};
+    hipLaunchKernelGGL(gather_rows3_kernel, dim3((int)cdiv(Rc, 256)), dim3(256), 0, stream, x, Np, argidx, Rc, 512, L.xc);
+    const float* in = L.xc;
+    for (int l = 1; l <= 4; ++l) {
+        TRY(op.lin_fwd(in, 0, kEnc[l - 1], w->conv_w[l - 1], 0, w->conv_b[l - 1], 0, L.hc[l], 0, kEnc[l], (int)Rc, kEnc[l],
+                       kEnc[l - 1], 1, true));
+        in = L.hc[l];
+    }
+    HP_RETURN_LAST_ERROR();
+}
+
 // Gradients of every encoder parameter.  grad_out: d/d z (VAE) or d/d mu (plain); grad_mu / grad_explv:
-// direct gradients on the VAE's mu / exp(logvar) outputs (KLD term), may be NULL.
+// direct gradients on the VAE's mu / exp(logvar) outputs (KLD term), may be NULL.  prepared != 0: `ws` already
+// holds the recomputed critical-row activations (hp_encoder_backward_prepare).
 HP_API int hp_encoder_backward(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size, int is_vae,
                                const float* eps, const int* argidx, const float* g, const float* f, const float* lv,
                                const float* grad_out, const float* grad_mu, const float* grad_explv,
-                               const HpEncoderGrads* gr, float* ws, hipStream_t stream) {
+                               const HpEncoderGrads* gr, float* ws, int prepared, hipStream_t stream) {
     HP_CHECK_ARG(B > 0 && Np > 0 && out_size > 0 && x && w && argidx && g && f && gr && ws);
     HP_CHECK_ARG(grad_out || grad_mu || grad_explv);
     HP_CHECK_ARG(!is_vae || (eps && lv));
     const long Rc = (long)B * 512;
-    float* p = ws;
-    auto take = [&](long n) { float* r = p; p += (n + 3) / 4 * 4; return r; };
-    float* xc = take(Rc * 3);
-    float* hc[5];
-    for (int l = 1; l <= 4; ++l) hc[l] = take(Rc * kEnc[l]);
-    float* dl[5];
-    for (int l = 1; l <= 4; ++l) dl[l] = take(Rc * kEnc[l]);
-    float* dmu = take((long)B * out_size);
-    float* dlv = take((long)B * out_size);
-    float* tmp = take((long)B * 512);
-    float* dfc = take((long)B * 512);
-    float* dg = take((long)B * 512);
-    Op op{stream, take(kSplitWs)};
+    EncBwdWs L = enc_bwd_layout(ws, B, out_size);
+    float* xc = L.xc;
+    float** hc = L.hc;
+    float** dl = L.dl;
+    float *dmu = L.dmu, *dlv = L.dlv, *tmp = L.tmp, *dfc = L.dfc, *dg = L.dg;
+    Op op{stream, L.split};
+    if (!prepared) TRY(hp_encoder_backward_prepare(B, Np, x, w, out_size, argidx, ws, stream));
 
     // ---- heads (model/encoder.py:46-53)
     const float* dmu_p;
@@ -340,13 +380,6 @@ HP_API int hp_encoder_backward(int B, int Np, const float* x, const HpEncoderWei
     TRY(op.lin_dx(dfc, 0, 512, w->fc_w, 0, dg, 0, 512, B, 512, 512, 1, nullptr, 0, 0, nullptr, 0));
 
     // ---- conv stack on the B*512 critical rows
-    hipLaunchKernelGGL(gather_rows3_kernel, dim3((int)cdiv(Rc, 256)), dim3(256), 0, stream, x, Np, argidx, Rc, 512, xc);
-    const float* in = xc;
-    for (int l = 1; l <= 4; ++l) {
-        TRY(op.lin_fwd(in, 0, kEnc[l - 1], w->conv_w[l - 1], 0, w->conv_b[l - 1], 0, hc[l], 0, kEnc[l], (int)Rc, kEnc[l],
-                       kEnc[l - 1], 1, true));
-        in = hc[l];
-    }
     hipLaunchKernelGGL(enc_l5_bwd_kernel, dim3(512), dim3(256), 0, stream, B, 512, 512, dg, w->conv_w[4], hc[4], gr->conv_w[4],
                        dl[4], gr->conv_b[4]);
     for (int l = 4; l >= 1; --l) {

@@ -178,10 +178,14 @@ int hp_encoder_forward(int B, int Np, const float* x, const HpEncoderWeights* w,
 /* Gradients of every encoder parameter (autograd of the above).  grad_out = d/dz (VAE) or d/dmu (plain);
  * grad_mu / grad_explv = direct gradients on the VAE outputs (may be NULL). */
 long hp_encoder_backward_workspace_floats(int B, int out_size);
+/* gradient-independent half (gather of the critical rows + recomputation of their activations into ws): may run
+ * early, on another stream; then pass prepared = 1 below */
+int hp_encoder_backward_prepare(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size,
+                                const int* argidx, float* ws, hpStream_t stream);
 int hp_encoder_backward(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size, int is_vae,
                         const float* eps, const int* argidx, const float* g, const float* f, const float* lv,
                         const float* grad_out, const float* grad_mu, const float* grad_explv, const HpEncoderGrads* grads,
-                        float* ws, hpStream_t stream);
+                        float* ws, int prepared, hpStream_t stream);
 
 /* HyperNetwork.forward (model/hyper_network.py:41-43): latent (B,in) -> theta (B,theta_ld); t = saved trunk
  * activations (hp_hypernet_saved_floats floats) for the backward. */
