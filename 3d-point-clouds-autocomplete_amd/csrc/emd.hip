@@ -50,7 +50,13 @@ __host__ __device__ constexpr float level_l2e(int lev) {
             : lev == 5 ? -16.f : lev == 6 ? -4.f : lev == 7 ? -1.f : -0.25f) * kLog2e;
 }
 
-inline int pad_up(int x) { return (x + 2 * kStage - 1) / (2 * kStage) * (2 * kStage); }
+// Only B*N row points exist (2 waves per SIMD at B=64, N=2048): to fill the SIMDs each row's candidate sweep is cut
+// into kParts contiguous ranges handled by different waves of the workgroup and added in range order through LDS
+// (ordered, deterministic; a reordering of the reference's sequential sum that moves the cost by ~1e-7 relative —
+// measured on the oracle — against 1e-5 for the exp formulation).
+constexpr int kParts = 4;
+constexpr int kRowsPerWg = kThreads / kParts;
+inline int pad_up(int x) { return (x + 2 * kStage * kParts - 1) / (2 * kStage * kParts) * (2 * kStage * kParts); }
 
 // per-cloud workspace (floats), every candidate array padded to NP/MP (+kSpare) entries:
 //   PLP  pair records of set1 for phase 2:        8 floats per PAIR  [x0 x1 y0 y1 z0 z1 ratioL0 ratioL1]
@@ -137,8 +143,11 @@ __device__ __forceinline__ f2 exp2_2(f2 a) { return f2{__builtin_amdgcn_exp2f(a.
 //               DO1: phase 1 of level lev1 (ratioL, :60-93).  Candidates: PRP (+RR) records on the scalar path.
 template <bool DO3, bool DO1>
 __global__ __launch_bounds__(kThreads) void emd_rows1_kernel(Ctx c, int lev1, float l2e3, float l2e1) {
+    __shared__ float part3[kParts][kRowsPerWg], part1[kParts][kRowsPerWg];
     const int cloud = blockIdx.y;
-    const int k = blockIdx.x * kThreads + threadIdx.x;
+    const int lrow = threadIdx.x % kRowsPerWg;
+    const int part = __builtin_amdgcn_readfirstlane(threadIdx.x / kRowsPerWg);   // wave-uniform
+    const int k = blockIdx.x * kRowsPerWg + lrow;
     float* ws = c.ws + (long)cloud * c.per_cloud;
     float* remL = c.temp + (long)cloud * (c.n + c.m) * 2;
     float* ratioL = remL + c.n + c.m;
@@ -152,9 +161,10 @@ __global__ __launch_bounds__(kThreads) void emd_rows1_kernel(Ctx c, int lev1, fl
         if (DO3) rl = ratioL[k];
     }
     const f2 px2 = splat(px), py2 = splat(py), pz2 = splat(pz), rl2 = splat(rl), l3 = splat(l2e3), l1 = splat(l2e1);
-    float acc3 = 0.f, acc1 = 1e-9f;
-    const float* p = ws + c.prp;   // wave-uniform
-    const float* q = ws + c.rr;
+    float acc3 = 0.f, acc1 = part == 0 ? 1e-9f : 0.f;
+    const int cand = c.MP / kParts;                                  // candidates of this wave's range
+    const float* p = ws + c.prp + (long)part * cand * 4;   // wave-uniform
+    const float* q = ws + c.rr + (long)part * cand;
     f32x16 a0, a1, b0, b1;
     f32x8 w0 = {}, w1 = {};
     auto work = [&](const f32x16& lo, const f32x16& hi, const f32x8& w) {
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(kThreads) void emd_rows1_kernel(Ctx c, int lev1, fl
     HP_SLOAD16(a1, p, 0x40);
     if (DO1) HP_SLOAD8(w0, q, 0x0);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+s"(w0));
-    for (int l0 = 0; l0 < c.MP; l0 += 2 * kStage) {
+    for (int l0 = 0; l0 < cand; l0 += 2 * kStage) {
         p += kStage * 4;
         q += kStage;
         HP_SLOAD16(b0, p, 0x0);
@@ -195,7 +205,15 @@ __global__ __launch_bounds__(kThreads) void emd_rows1_kernel(Ctx c, int lev1, fl
         work(b0, b1, w1);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+s"(w0), "+v"(acc3), "+v"(acc1));
     }
-    if (!ok) return;
+    part3[part][lrow] = acc3;
+    part1[part][lrow] = acc1;
+    __syncthreads();
+    if (part != 0 || !ok) return;
+#pragma unroll
+    for (int q2 = 1; q2 < kParts; ++q2) {
+        acc3 += part3[q2][lrow];
+        acc1 += part1[q2][lrow];
+    }
     float rem = remL[k];
     if (DO3) {
         rem = fmaxf(0.0f, rem - acc3);
@@ -211,8 +229,11 @@ __global__ __launch_bounds__(kThreads) void emd_rows1_kernel(Ctx c, int lev1, fl
 
 // Rows = set2: phase 2 (ratioR / remainR update, approxmatch.cu:109-142).  Candidates: PLP records.
 __global__ __launch_bounds__(kThreads) void emd_rows2_kernel(Ctx c, int lev, float l2e) {
+    __shared__ float parts[kParts][kRowsPerWg];
     const int cloud = blockIdx.y;
-    const int l = blockIdx.x * kThreads + threadIdx.x;
+    const int lrow = threadIdx.x % kRowsPerWg;
+    const int part = __builtin_amdgcn_readfirstlane(threadIdx.x / kRowsPerWg);
+    const int l = blockIdx.x * kRowsPerWg + lrow;
     float* ws = c.ws + (long)cloud * c.per_cloud;
     float* remR = c.temp + (long)cloud * (c.n + c.m) * 2 + c.n;
     float* ratioR = remR + c.m + c.n;
@@ -226,7 +247,8 @@ __global__ __launch_bounds__(kThreads) void emd_rows2_kernel(Ctx c, int lev, flo
     }
     const f2 qx2 = splat(qx), qy2 = splat(qy), qz2 = splat(qz), lv = splat(l2e);
     float acc = 0.f;
-    const float* p = ws + c.plp;
+    const int cand = c.NP / kParts;
+    const float* p = ws + c.plp + (long)part * cand * 4;
     f32x16 a0, a1, b0, b1;
     auto work = [&](const f32x16& lo, const f32x16& hi) {
 #pragma unroll
@@ -241,7 +263,7 @@ __global__ __launch_bounds__(kThreads) void emd_rows2_kernel(Ctx c, int lev, flo
     HP_SLOAD16(a0, p, 0x0);
     HP_SLOAD16(a1, p, 0x40);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1));
-    for (int k0 = 0; k0 < c.NP; k0 += 2 * kStage) {
+    for (int k0 = 0; k0 < cand; k0 += 2 * kStage) {
         p += kStage * 4;
         HP_SLOAD16(b0, p, 0x0);
         HP_SLOAD16(b1, p, 0x40);
@@ -255,7 +277,11 @@ __global__ __launch_bounds__(kThreads) void emd_rows2_kernel(Ctx c, int lev, flo
         work(b0, b1);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(acc));
     }
-    if (!ok) return;
+    parts[part][lrow] = acc;
+    __syncthreads();
+    if (part != 0 || !ok) return;
+#pragma unroll
+    for (int q2 = 1; q2 < kParts; ++q2) acc += parts[q2][lrow];
     const float rr = remR[l];
     const float sumr = acc * rr;
     const float consumption = fminf(rr / (sumr + 1e-9f), 1.0f);
@@ -471,7 +497,7 @@ int run_levels(int b, int n, int m, const float* xyz1, const float* xyz2, float*
         multiL = (float)(m / n);
         multiR = 1;
     }
-    const dim3 g1((n + kThreads - 1) / kThreads, b), g2((m + kThreads - 1) / kThreads, b);
+    const dim3 g1((n + kRowsPerWg - 1) / kRowsPerWg, b), g2((m + kRowsPerWg - 1) / kRowsPerWg, b);
     hipLaunchKernelGGL(emd_init_kernel, dim3((L.NP + L.MP + 2 * kSpare + kThreads - 1) / kThreads, b), dim3(kThreads), 0, stream, c, multiL, multiR);
     hipLaunchKernelGGL((emd_rows1_kernel<false, true>), g1, dim3(kThreads), 0, stream, c, 0, 0.f, level_l2e(0));
     for (int lev = 0; lev < kLevels; ++lev) {

@@ -50,7 +50,7 @@ def test_workspace_queries_run_on_host(lib):
     lib.hp_target_theta_size.restype = ctypes.c_long
     # packed candidate records of emd.hip: (N+8)*(4+16) + (M+8)*(4+1+16) floats per cloud, N and M padded to 16
     assert lib.hp_approxmatch_workspace_floats(64, 2048, 2048) == 64 * (2056 * 20 + 2056 * 21)
-    assert lib.hp_approxmatch_workspace_floats(1, 100, 37) == (112 + 8) * 20 + (48 + 8) * 21
+    assert lib.hp_approxmatch_workspace_floats(1, 100, 37) == (128 + 8) * 20 + (64 + 8) * 21   # padded to multiples of 64
     ch = (ctypes.c_int * 4)(32, 64, 128, 64)
     assert lib.hp_target_theta_size(4, ch) == 19011
     assert lib.hp_target_theta_size(0, ch) == -1
