@@ -365,8 +365,11 @@ __global__ __launch_bounds__(kThreads) void emd_match_kernel(Ctx c, float* __res
 // (approxmatch.cu:215-255, 301-322 without the match tensor).  One lane per k, all l on the scalar path.
 __global__ __launch_bounds__(kThreads) void emd_cost_grad1_kernel(Ctx c, float* __restrict__ partials, float* __restrict__ grad1) {
     __shared__ float red[kThreads / 64];
+    __shared__ float parts[kParts][4][kRowsPerWg];
     const int cloud = blockIdx.y;
-    const int k = blockIdx.x * kThreads + threadIdx.x;
+    const int lrow = threadIdx.x % kRowsPerWg;
+    const int part = __builtin_amdgcn_readfirstlane(threadIdx.x / kRowsPerWg);
+    const int k = blockIdx.x * kRowsPerWg + lrow;
     const float* ws = c.ws + (long)cloud * c.per_cloud;
     const bool ok = k < c.n;
     float px = 0.f, py = 0.f, pz = 0.f, rL[kLevels] = {};
@@ -387,12 +390,13 @@ __global__ __launch_bounds__(kThreads) void emd_cost_grad1_kernel(Ctx c, float* 
         dz = __builtin_fmaf(ez.x, w.x, dz);
         dz = __builtin_fmaf(ez.y, w.y, dz);
     };
-    const float* p = ws + c.frp;
+    const int cand = c.MP / kParts;
+    const float* p = ws + c.frp + (long)part * cand * 16;
     f32x16 a0, a1, b0, b1;
     HP_SLOAD16(a0, p, 0x0);
     HP_SLOAD16(a1, p, 0x40);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1));
-    for (int l = 0; l < c.MP; l += 4) {
+    for (int l = 0; l < cand; l += 4) {
         p += 32;
         HP_SLOAD16(b0, p, 0x0);
         HP_SLOAD16(b1, p, 0x40);
@@ -406,13 +410,27 @@ __global__ __launch_bounds__(kThreads) void emd_cost_grad1_kernel(Ctx c, float* 
         work(b0, b1);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(cost), "+v"(dx), "+v"(dy), "+v"(dz));
     }
-    if (ok && grad1) {
-        float* g = grad1 + ((long)cloud * c.n + k) * 3;
-        g[0] = dx;
-        g[1] = dy;
-        g[2] = dz;
+    parts[part][0][lrow] = dx;
+    parts[part][1][lrow] = dy;
+    parts[part][2][lrow] = dz;
+    parts[part][3][lrow] = cost;
+    __syncthreads();
+    if (part == 0) {
+#pragma unroll
+        for (int q2 = 1; q2 < kParts; ++q2) {
+            dx += parts[q2][0][lrow];
+            dy += parts[q2][1][lrow];
+            dz += parts[q2][2][lrow];
+            cost += parts[q2][3][lrow];
+        }
+        if (ok && grad1) {
+            float* g = grad1 + ((long)cloud * c.n + k) * 3;
+            g[0] = dx;
+            g[1] = dy;
+            g[2] = dz;
+        }
     }
-    const float t = hp::block_sum(ok ? cost : 0.f, red);
+    const float t = hp::block_sum((ok && part == 0) ? cost : 0.f, red);
     if (threadIdx.x == 0) partials[(long)cloud * gridDim.x + blockIdx.x] = t;
 }
 
@@ -422,8 +440,11 @@ __global__ __launch_bounds__(kThreads) void emd_cost_grad1_kernel(Ctx c, float* 
 template <bool WITH_COST>
 __global__ __launch_bounds__(kThreads) void emd_grad2_kernel(Ctx c, float* __restrict__ grad2, float* __restrict__ partials) {
     __shared__ float red[kThreads / 64];
+    __shared__ float parts[kParts][4][kRowsPerWg];
     const int cloud = blockIdx.y;
-    const int l = blockIdx.x * kThreads + threadIdx.x;
+    const int lrow = threadIdx.x % kRowsPerWg;
+    const int part = __builtin_amdgcn_readfirstlane(threadIdx.x / kRowsPerWg);
+    const int l = blockIdx.x * kRowsPerWg + lrow;
     const float* ws = c.ws + (long)cloud * c.per_cloud;
     const bool ok = l < c.m;
     float qx = 0.f, qy = 0.f, qz = 0.f, rR[kLevels] = {};
@@ -446,12 +467,13 @@ __global__ __launch_bounds__(kThreads) void emd_grad2_kernel(Ctx c, float* __res
         sz = __builtin_fmaf(ez.x, w.x, sz);
         sz = __builtin_fmaf(ez.y, w.y, sz);
     };
-    const float* p = ws + c.flp;
+    const int cand = c.NP / kParts;
+    const float* p = ws + c.flp + (long)part * cand * 16;
     f32x16 a0, a1, b0, b1;
     HP_SLOAD16(a0, p, 0x0);
     HP_SLOAD16(a1, p, 0x40);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1));
-    for (int k = 0; k < c.NP; k += 4) {
+    for (int k = 0; k < cand; k += 4) {
         p += 32;
         HP_SLOAD16(b0, p, 0x0);
         HP_SLOAD16(b1, p, 0x40);
@@ -465,14 +487,28 @@ __global__ __launch_bounds__(kThreads) void emd_grad2_kernel(Ctx c, float* __res
         work(b0, b1);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(sx), "+v"(sy), "+v"(sz), "+v"(cost));
     }
-    if (ok) {
-        float* g = grad2 + ((long)cloud * c.m + l) * 3;
-        g[0] = sx;
-        g[1] = sy;
-        g[2] = sz;
+    parts[part][0][lrow] = sx;
+    parts[part][1][lrow] = sy;
+    parts[part][2][lrow] = sz;
+    parts[part][3][lrow] = cost;
+    __syncthreads();
+    if (part == 0) {
+#pragma unroll
+        for (int q2 = 1; q2 < kParts; ++q2) {   // candidate ranges in ascending order
+            sx += parts[q2][0][lrow];
+            sy += parts[q2][1][lrow];
+            sz += parts[q2][2][lrow];
+            cost += parts[q2][3][lrow];
+        }
+        if (ok) {
+            float* g = grad2 + ((long)cloud * c.m + l) * 3;
+            g[0] = sx;
+            g[1] = sy;
+            g[2] = sz;
+        }
     }
     if (WITH_COST) {
-        const float t = hp::block_sum(ok ? cost : 0.f, red);
+        const float t = hp::block_sum((ok && part == 0) ? cost : 0.f, red);
         if (threadIdx.x == 0) partials[(long)cloud * gridDim.x + blockIdx.x] = t;
     }
 }
@@ -535,7 +571,7 @@ HP_API int hp_approxmatch(int b, int n, int m, const float* xyz1, const float* x
 // Match-free EMD forward (what match_cost's forward = ApproxMatch + MatchCost computes, match_cost.py:9-27):
 // cost (b,) and, as a by-product of the same sweep, grad1 = d cost / d xyz1 (b,n,3) (may be NULL).
 // `ws` keeps the packed records for hp_emd_backward; partials: b*ceil(n/256) floats.
-HP_API long hp_emd_partials_floats(int b, int n, int m) { return (long)b * ((std::max(n, m) + kThreads - 1) / kThreads); }
+HP_API long hp_emd_partials_floats(int b, int n, int m) { return (long)b * ((std::max(n, m) + kRowsPerWg - 1) / kRowsPerWg); }
 
 // grad1 / grad2 (either may be NULL): gradients to produce in the same call.  With grad2 != NULL the cost rides on the
 // grad2 sweep (one evaluation of the match entries serves both); grad1 then costs a second sweep only if requested.
@@ -547,7 +583,7 @@ HP_API int hp_emd_forward(int b, int n, int m, const float* xyz1, const float* x
     Ctx c;
     int rc = run_levels(b, n, m, xyz1, xyz2, temp, ws, &c, stream);
     if (rc) return rc;
-    const int nb = (n + kThreads - 1) / kThreads, mb = (m + kThreads - 1) / kThreads;
+    const int nb = (n + kRowsPerWg - 1) / kRowsPerWg, mb = (m + kRowsPerWg - 1) / kRowsPerWg;
     if (grad2) {
         hipLaunchKernelGGL(emd_grad2_kernel<true>, dim3(mb, b), dim3(kThreads), 0, stream, c, grad2, partials);
         hipLaunchKernelGGL(emd_cost_finish_kernel, dim3(b), dim3(256), 0, stream, partials, mb, cost);
@@ -568,6 +604,6 @@ HP_API int hp_emd_backward(int b, int n, int m, const float* xyz1, const float* 
     HP_CHECK_ARG(ws && grad2 && b <= 65535);
     const WsLayout L = ws_layout(n, m);
     Ctx c{n, m, L.NP, L.MP, xyz1, xyz2, nullptr, const_cast<float*>(ws), L.plp, L.prp, L.rr, L.flp, L.frp, L.per_cloud};
-    hipLaunchKernelGGL(emd_grad2_kernel<false>, dim3((m + kThreads - 1) / kThreads, b), dim3(kThreads), 0, stream, c, grad2, nullptr);
+    hipLaunchKernelGGL(emd_grad2_kernel<false>, dim3((m + kRowsPerWg - 1) / kRowsPerWg, b), dim3(kThreads), 0, stream, c, grad2, nullptr);
     HP_RETURN_LAST_ERROR();
 }
