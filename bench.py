@@ -89,13 +89,15 @@ def roofline_dominant_kernel(batch, n_half):
             "algorithmic_bytes_per_launch": (2 * m * 512 + 512 * 512 + 512) * 4}
 
 
-def cpu_baseline(n_half, sample_b=4, timed_steps=2):
-    """The oracle (oracle/hyperpocket_ref.py: torch-CPU restatement of the reference step, kind "port") on a
-    bounded sample: `sample_b` clouds of the same per-cloud shape, 1 warm-up + `timed_steps` timed steps."""
+def cpu_baseline(n_half, emd_coef, sample_b=4, timed_steps=2):
+    """The oracle (oracle/hyperpocket_ref.py: torch-CPU restatement of the reference step + the C restatement of the
+    EMD kernels, kind "port") on a bounded sample of the SAME workload: `sample_b` clouds of the same per-cloud shape,
+    same loss terms, 1 warm-up + `timed_steps` timed steps."""
     from oracle import hyperpocket_ref as ref
     # torch's CPU kernels stop scaling (and thrash across NUMA domains) far below a 256-core host: 16 threads
     threads = min(16, os.cpu_count() or 1)
     torch.set_num_threads(threads)
+    os.environ["OMP_NUM_THREADS"] = str(threads)      # the C EMD oracle parallelises over clouds
     P = ref.init_params(2020)
     opt = ref.Adam(P)
     g = torch.Generator().manual_seed(2020)
@@ -106,14 +108,15 @@ def cpu_baseline(n_half, sample_b=4, timed_steps=2):
     def one():
         pts = torch.stack([ref.generate_points(1, 2 * n_half) for _ in range(sample_b)])   # CPU draws, as the reference
         eps = torch.randn(sample_b, 128)
-        ref.train_step(P, opt, ex, mi, gt, pts, eps)
+        ref.train_step(P, opt, ex, mi, gt, pts, eps, emd_coef=emd_coef)
     one()
     t0 = time.perf_counter()
     for _ in range(timed_steps):
         one()
     dt = (time.perf_counter() - t0) / timed_steps
     return {"value": round(sample_b / dt, 3), "unit": "clouds/s", "cores": threads, "kind": "port",
-            "sample": f"{timed_steps} timed steps (after 1 warm-up) of the oracle train step (Chamfer+KLD, Adam) at B={sample_b}, "
+            "sample": f"{timed_steps} timed steps (after 1 warm-up) of the oracle train step (0.05*Chamfer + KLD/B"
+                      f"{' + 0.05*EMD/N' if emd_coef else ''}, Adam) at B={sample_b}, "
                       f"existing/missing ({sample_b},{n_half},3), gt ({sample_b},{2 * n_half},3); {dt:.2f} s/step"}
 
 
@@ -213,7 +216,7 @@ def main():
                     line["breakdown"] = {"chamfer_only_ms_per_step": round(ms2, 4),
                                          "chamfer_only_clouds_per_s": round(args.batch / (ms2 * 1e-3), 2)}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(n_half)
+            line["cpu_baseline"] = cpu_baseline(n_half, emd_coef)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -153,6 +153,54 @@ def chamfer_loss(preds, gts):
     return torch.min(Pm, 1)[0].sum() + torch.min(Pm, 2)[0].sum()
 
 
+class _OracleEMD(torch.autograd.Function):
+    """match_cost (utils/pytorch_structural_losses/match_cost.py:5-48) on CPU through the C restatement
+    (oracle/libstructural_losses_ref.so): forward = ApproxMatch + MatchCost, backward = MatchCostGrad * grad."""
+
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            import ctypes
+            import os
+            import subprocess
+            here = os.path.dirname(os.path.abspath(__file__))
+            so = os.path.join(here, "libstructural_losses_ref.so")
+            if not os.path.exists(so):
+                subprocess.check_call(["make", "-C", here])
+            cls._lib = ctypes.CDLL(so)
+        return cls._lib
+
+    @staticmethod
+    def forward(ctx, a, b):
+        import ctypes
+        a, b = a.detach().contiguous().float(), b.detach().contiguous().float()
+        B, n, m = a.shape[0], a.shape[1], b.shape[1]
+        match, temp, out = torch.empty(B, m, n), torch.empty(B, 2 * (n + m)), torch.empty(B)
+        P = lambda t: ctypes.c_void_p(t.data_ptr())
+        lib = _OracleEMD.lib()
+        lib.ref_approxmatch(B, n, m, P(a), P(b), P(match), P(temp))
+        lib.ref_matchcost(B, n, m, P(a), P(b), P(match), P(out))
+        ctx.save_for_backward(a, b, match)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        a, b, match = ctx.saved_tensors
+        B, n, m = a.shape[0], a.shape[1], b.shape[1]
+        g1, g2 = torch.empty(B, n, 3), torch.empty(B, m, 3)
+        P = lambda t: ctypes.c_void_p(t.data_ptr())
+        _OracleEMD.lib().ref_matchcostgrad(B, n, m, P(a), P(b), P(match), P(g1), P(g2))
+        ge = g.view(-1, 1, 1)
+        return g1 * ge, g2 * ge
+
+
+def match_cost(a, b):
+    return _OracleEMD.apply(a, b)
+
+
 def mode_of(P):
     has_rand = "random_encoder.fc.0.weight" in P
     has_real = "real_encoder.fc.0.weight" in P
@@ -191,14 +239,20 @@ def full_forward(P, existing, missing, points, eps=None, training=True, noise=No
     return rec, explv, mu, theta
 
 
-def step_loss(P, existing, missing, gt, points, eps, loss_coef=0.05):
-    """core/epoch_loops.py:23-31 -> (loss_all, loss_r, loss_kld, rec)"""
+def step_loss(P, existing, missing, gt, points, eps, loss_coef=0.05, emd_coef=0.0):
+    """core/epoch_loops.py:23-31 -> (loss_all, loss_r, loss_kld, rec).  emd_coef > 0 adds the bench's "Chamfer+EMD"
+    term emd_coef * sum_b match_cost(gt, rec)_b / N (utils/metrics.py:71-76 normalisation)."""
     rec, explv, mu, _ = full_forward(P, existing, missing, points, eps, training=True)
-    loss_r = torch.mean(loss_coef * chamfer_loss(gt, rec.permute(0, 2, 1)))
+    rec_n3 = rec.permute(0, 2, 1)
+    loss_r = torch.mean(loss_coef * chamfer_loss(gt, rec_n3))
+    loss_all = loss_r
+    kld = None
     if mode_of(P) == "HyperPocket":
         kld = 0.5 * (torch.exp(explv) + torch.square(mu) - 1 - explv).sum() / existing.shape[0]
-        return loss_r + kld, loss_r, kld, rec
-    return loss_r, loss_r, None, rec
+        loss_all = loss_all + kld
+    if emd_coef:
+        loss_all = loss_all + emd_coef * (match_cost(gt, rec_n3.contiguous()) / float(gt.shape[1])).sum()
+    return loss_all, loss_r, kld, rec
 
 
 class Adam:
@@ -224,10 +278,10 @@ class Adam:
             P[k].addcdiv_(self.m[k], denom, value=-self.lr / bc1)
 
 
-def train_step(P, opt, existing, missing, gt, points, eps, loss_coef=0.05):
+def train_step(P, opt, existing, missing, gt, points, eps, loss_coef=0.05, emd_coef=0.0):
     """One reference training step (core/epoch_loops.py:15-39) on the parameter dict P (in place)."""
     leaves = {k: v.detach().requires_grad_(True) for k, v in P.items()}
-    loss_all, loss_r, kld, rec = step_loss(leaves, existing, missing, gt, points, eps, loss_coef)
+    loss_all, loss_r, kld, rec = step_loss(leaves, existing, missing, gt, points, eps, loss_coef, emd_coef)
     loss_all.backward()
     grads = {k: v.grad for k, v in leaves.items()}
     opt.step(P, grads)

@@ -409,3 +409,29 @@ def test_train_engine_with_emd_term_runs_and_decreases_loss():
         assert last < first
     finally:
         ops.clear_grad_views()
+
+
+def test_train_engine_chamfer_plus_emd_step_vs_oracle(ref):
+    """The bench workload's step (0.05*Chamfer + KLD/B + 0.05*EMD/N, Adam) against the oracle's same step on CPU."""
+    from hyperpocket_amd.core.engine import TrainEngine
+    from hyperpocket_amd import ops
+    model = build_model(2020)
+    P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    opt = ref.Adam(P)
+    eng = TrainEngine(model, emd_coef=0.05)
+    try:
+        g = torch.Generator().manual_seed(4)
+        ex, mi = torch.rand(2, 80, 3, generator=g) - 0.5, torch.rand(2, 80, 3, generator=g) - 0.5
+        gt = torch.cat([ex, mi], 1)
+        pts, eps = torch.rand(2, 160, 3, generator=g) * 2 - 1, torch.randn(2, 128, generator=g)
+        out = eng.step(ex.cuda(), mi.cuda(), gt.cuda(), 30, points=pts.cuda(), eps_noise=eps.cuda())
+        loss_all, loss_r, kld, rec, grads = ref.train_step(P, opt, ex, mi, gt, pts, eps, emd_coef=0.05)
+        assert abs(out["loss_all"].item() - loss_all.item()) <= 1e-5 * abs(loss_all.item())
+        assert abs(out["loss_r"].item() - loss_r.item()) <= 1e-5 * abs(loss_r.item())
+        want_emd = loss_all.item() - loss_r.item() - kld.item()
+        assert abs(out["loss_emd"].item() - want_emd) <= 1e-3 * abs(want_emd) + 1e-2   # difference of large numbers on the oracle side
+        for k, p in model.named_parameters():
+            a, b = p.detach().cpu().double().norm().item(), P[k].double().norm().item()
+            assert abs(a - b) <= 1e-5 * b + 1e-9, k
+    finally:
+        ops.clear_grad_views()
