@@ -435,3 +435,51 @@ def test_train_engine_chamfer_plus_emd_step_vs_oracle(ref):
             assert abs(a - b) <= 1e-5 * b + 1e-9, k
     finally:
         ops.clear_grad_views()
+
+
+def test_baseline_config4_hyperrec_full_size_step(ref):
+    """BASELINE.json configs[3] per-GPU shape: Completion3D / HyperRec, partial cloud (B,2048,3), `missing` is the
+    collated int 0 (datasets/shapenet_completion3d.py:41-48).  Parity with the oracle at full N on 4 clouds, then the
+    full B=32 step for finiteness (an untrained net's first steps do not decrease monotonically — neither do the
+    reference's, tests/golden/train_steps.npz)."""
+    from hyperpocket_amd.core.engine import TrainEngine
+    from hyperpocket_amd import ops
+    model = build_model(5, 0, 128)
+    assert not model.mode.has_generativity() and sum(p.numel() for p in model.parameters()) == 42490499
+    P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    eng = TrainEngine(model)
+    try:
+        g = torch.Generator().manual_seed(2)
+        partial, gt = torch.rand(4, 2048, 3, generator=g) - 0.5, torch.rand(4, 2048, 3, generator=g) - 0.5
+        pts = torch.rand(4, 2048, 3, generator=g) * 2 - 1
+        out = eng.step(partial.cuda(), torch.zeros(4).cuda(), gt.cuda(), 101, points=pts.cuda())
+        loss_all, loss_r, kld, rec, _ = ref.train_step(P, ref.Adam(P), partial, None, gt, pts, None)
+        assert kld is None and "loss_kld" not in out
+        assert abs(out["loss_all"].item() - loss_all.item()) <= 1e-5 * abs(loss_all.item())
+        for k, p in model.named_parameters():
+            a, b = p.detach().cpu().double().norm().item(), P[k].double().norm().item()
+            assert abs(a - b) <= 1e-5 * b + 1e-9, k
+        gd = torch.Generator(device="cuda").manual_seed(2)
+        partial = torch.rand(32, 2048, 3, device="cuda", generator=gd) - 0.5
+        gt = torch.rand(32, 2048, 3, device="cuda", generator=gd) - 0.5
+        losses = [eng.step(partial, torch.zeros(32, device="cuda"), gt, 101)["loss_all"].item() for _ in range(3)]
+        assert all(np.isfinite(losses)) and partial.shape == (32, 2048, 3)
+    finally:
+        ops.clear_grad_views()
+
+
+def test_baseline_config5_chamfer_stress_shape():
+    """BASELINE.json configs[4] per-GPU shape: 64 clouds of 8192 points, Chamfer forward + backward."""
+    from hyperpocket_amd.losses.champfer_loss import ChamferLoss
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.rand(64, 8192, 3, device="cuda", generator=g) - 0.5
+    y = (torch.rand(64, 8192, 3, device="cuda", generator=g) - 0.5).requires_grad_(True)
+    L = ChamferLoss()
+    lxy = L(x, y)
+    lxy.backward()
+    assert abs(lxy.item() - L(y.detach(), x).item()) <= 1e-6 * lxy.item()
+    assert torch.isfinite(y.grad).all() and y.grad.abs().sum().item() > 0
+    # gradient of a sum of squared distances: translating y by t changes the loss by <grad, t> to first order
+    t = torch.tensor([1e-4, -2e-4, 5e-5], device="cuda")
+    fd = (L(x, y.detach() + t) - L(x, y.detach() - t)).item() / 2
+    assert abs(fd - (y.grad * t).sum().item()) <= 2e-2 * abs(fd) + 1e-3
