@@ -25,6 +25,8 @@ class TrainEngine:
         self.exp_avg = torch.zeros_like(self.flat.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat.flat)
         self.steps = 0
+        self._heads_pending = False
+        model._pre_hypernet_hook = self.finish_pending     # FullModel.forward calls it right before the hypernetwork
         self.chamfer = ChamferLoss()
         if self.world > 1:
             # replicas start from rank 0's weights
@@ -81,11 +83,32 @@ class TrainEngine:
             # enqueued; ship them while the encoders' backward still runs
             self._install_overlap_hook()
         loss_all.backward()
-        self.reducer.finish()
         self.steps += 1
-        ops.adam_step(self.flat.flat, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
-                      self.eps, self.steps)
+        # Exchange + update per bucket.  Trunk and encoders (17 MB) are reduced and updated now; the hypernetwork heads
+        # (156 MB, 90 % of the bytes) are only needed again in the NEXT step's hypernetwork forward, which comes after
+        # ~1 ms of encoder forward: their all-reduce stays in flight across the step boundary and `finish_pending`
+        # (called by FullModel.forward right before the hypernetwork) waits for it and applies their Adam update there.
+        self.reducer.launch_all()
+        for b in range(1, len(self.flat.buckets)):
+            self.reducer.wait(b)
+            self._adam(b)
+        if self.world > 1:
+            self._heads_pending = True
+        else:
+            self._adam(0)
         return out
+
+    def _adam(self, bucket):
+        lo, hi = self.flat.buckets[bucket]
+        ops.adam_step(self.flat.flat[lo:hi], self.flat.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.lr,
+                      self.betas[0], self.betas[1], self.eps, self.steps)
+
+    def finish_pending(self):
+        """Complete the deferred heads update (idempotent).  Call before reading the parameters outside `step`."""
+        if self._heads_pending:
+            self.reducer.wait(0)
+            self._adam(0)
+            self._heads_pending = False
 
     def _install_overlap_hook(self):
         # fires when autograd has finished the HyperNetFunction node, i.e. when the gradient w.r.t. the latent exists

@@ -93,6 +93,9 @@ class FullModel(nn.Module):
 
         latent, mu, logvar = self.mode.get_latent(self, existing, missing, noise, eps)
         self._last_latent = latent   # TrainEngine hooks its gradient: "hypernetwork backward has been enqueued"
+        hook = self.__dict__.get("_pre_hypernet_hook")
+        if hook is not None:
+            hook()                   # TrainEngine: deferred all-reduce wait + Adam of the hypernetwork heads
 
         target_networks_weights = self.hyper_network(latent)
         batch, n_points = target_networks_weights.size(0), gt_shape[2]

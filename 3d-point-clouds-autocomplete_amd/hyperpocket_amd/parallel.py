@@ -79,7 +79,7 @@ class GradientReducer:
     def __init__(self, flat: FlatParameters, process_group=None):
         self.flat, self.pg = flat, process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.pending = []
+        self.works = {}
         self.launched = set()
 
     def launch(self, bucket):
@@ -87,12 +87,19 @@ class GradientReducer:
             return
         lo, hi = self.flat.buckets[bucket]
         self.launched.add(bucket)
-        self.pending.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        self.works[bucket] = dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
-    def finish(self):
+    def launch_all(self):
         for b in range(len(self.flat.buckets)):
             self.launch(b)
-        for w in self.pending:
-            w.wait()
-        self.pending.clear()
-        self.launched.clear()
+
+    def wait(self, bucket):
+        """Make the current stream wait for `bucket`'s all-reduce (no-op if it was not launched / world == 1)."""
+        if bucket in self.launched:
+            self.works.pop(bucket).wait()
+            self.launched.discard(bucket)
+
+    def finish(self):
+        self.launch_all()
+        for b in list(self.launched):
+            self.wait(b)

@@ -161,6 +161,7 @@ def main():
     ex, mi, gt = synth_batch(args.batch, n_half, device, 2020 + rank)
 
     def sync():
+        engine.finish_pending()     # the heads' all-reduce + Adam of the last step (deferred across the step boundary)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

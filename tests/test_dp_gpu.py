@@ -59,6 +59,7 @@ def _worker(rank, world, port, out):
     for _ in range(2):
         res = eng.step(ex[sl].contiguous(), mi[sl].contiguous(), gt[sl].contiguous(), 7, points=pts[sl].contiguous(),
                        eps_noise=eps[sl].contiguous())
+    eng.finish_pending()       # the heads' exchange/update is deferred into the next step; flush it before reading
     torch.cuda.synchronize()
     if rank == 0:   # by file: a 173 MB dict does not travel well through an mp.Queue once the sender exits
         torch.save({k: p.detach().cpu() for k, p in model.named_parameters()}, out)
