@@ -135,11 +135,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Test hook (not used by the driver): HP_BENCH_BACKEND=gloo HP_BENCH_ONE_DEVICE=1 exercises the multi-rank code
+    # path with every rank on cuda:0, so that it can be checked on a 1-GPU box.
+    backend = os.environ.get("HP_BENCH_BACKEND", "nccl")
+    if os.environ.get("HP_BENCH_ONE_DEVICE"):
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     if args.gpus != world and rank == 0 and world > 1:
