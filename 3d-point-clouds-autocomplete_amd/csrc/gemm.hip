@@ -469,7 +469,7 @@ HP_API int hp_gemm_f32(const HpGemmDesc* d, hipStream_t stream) {
         case 0: rc = launch_cfg<128, 32, 4, 1, 16>(p, d->batch, stream); break;
         case 1: rc = launch_cfg<128, 128, 2, 2, 16>(p, d->batch, stream); break;
         case 2: rc = launch_cfg<64, 128, 2, 2, 16>(p, d->batch, stream); break;
-        default: rc = launch_cfg<64, 64, 2, 2, 16>(p, d->batch, stream); break;
+        default: rc = launch_cfg<64, 64, 2, 2, 32>(p, d->batch, stream); break;
     }
     if (rc) return rc;
     if (p.ksplit > 1) {

@@ -1,5 +1,10 @@
 #!/usr/bin/env python3
-"""Times hp_gemm_f32 of experimental builds (tools/exp/*.so) on the encoder conv5 shape."""
+"""Times hp_gemm_f32 of experimental builds (tools/exp/*.so) on the encoder conv5 shape.
+
+Used in round 1 to A/B kernel variants built with -D flags from csrc/gemm.hip into tools/exp/ (generic vs branch-free
+loaders: 85 -> 113 TFLOP/s; BK 16 vs 32; s_setprio; no-load ceiling 122 TFLOP/s).  Build a variant with
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -shared csrc/gemm.hip -o tools/exp/gemm_x.so
+"""
 import ctypes, glob, os, sys
 import torch
 from ctypes import c_int, c_long, c_void_p
