@@ -168,3 +168,44 @@ def test_two_rank_gradient_exchange_equals_global_batch_gradient():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert worst < 2e-3, worst     # fp32 summation-order noise (incl. arg-max near-ties) only
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/core"), reason="reference tree only exists in the build container")
+def test_reference_train_epoch_binds_to_this_package_unmodified():
+    """with the module aliases installed, the reference's own core/epoch_loops.py (read-only,
+    untouched) imports this package's FullModel and drives it; without a GPU the first kernel call refuses to run
+    (no CPU fallback) — which is as far as the wiring can be exercised here."""
+    import importlib
+    import subprocess
+    import sys
+    code = r"""
+import sys, importlib, copy, torch
+sys.dont_write_bytecode = True
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, "/root/reference")
+for ref_name, amd_name in {
+        "model.full_model": "hyperpocket_amd.model.full_model", "model.encoder": "hyperpocket_amd.model.encoder",
+        "model.hyper_network": "hyperpocket_amd.model.hyper_network", "model.target_network": "hyperpocket_amd.model.target_network",
+        "losses.champfer_loss": "hyperpocket_amd.losses.champfer_loss", "utils.points": "hyperpocket_amd.utils.points"}.items():
+    sys.modules[ref_name] = importlib.import_module(amd_name)
+import core.epoch_loops as el                      # the reference's file
+from hyperpocket_amd.model.full_model import FullModel
+from hyperpocket_amd.losses.champfer_loss import ChamferLoss
+from hyperpocket_amd import HipExtensionError
+assert el.FullModel is FullModel and el.__file__.startswith("/root/reference")
+sys.path.insert(0, %r)
+from test_host_logic import model_config
+m = FullModel(copy.deepcopy(model_config()))
+opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+ex, mi = torch.rand(2, 16, 3), torch.rand(2, 16, 3)
+try:
+    el.train_epoch(1, m, opt, [(ex, mi, torch.cat([ex, mi], 1), 0)], torch.device("cpu"), ChamferLoss(), 0.05)
+except HipExtensionError as e:
+    print("REFUSED:", str(e)[:60])
+else:
+    raise SystemExit("a CPU fallback ran")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+       os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "3d-point-clouds-autocomplete_amd"),
+       os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "REFUSED:" in out.stdout
