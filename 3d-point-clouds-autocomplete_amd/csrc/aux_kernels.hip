@@ -62,6 +62,102 @@ __global__ __launch_bounds__(256) void sample_points_kernel(long total, float co
     out[i * 3 + 2] = z;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Random-plane slicer (datasets/utils/dataset_generator.py:6-39): split a cloud into two parts of exactly
+// `target` and N - target points by a random plane, rejecting planes until one side has exactly `target` points.
+// One workgroup per cloud: points staged in LDS, four candidate planes per round (one per wave, Philox-drawn:
+// three uniform [0,1) points -> normal = cross product, bias = +dot(normal, p0) as the reference computes it),
+// the lowest-numbered accepting wave of the first accepting round wins (= the first accepted plane of an i.i.d.
+// sequence, as in the reference's while-loop), then an order-preserving compaction writes both parts.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kSliceMaxPts = 8192;
+
+__global__ __launch_bounds__(256) void slice_kernel(int N, int target, const float* __restrict__ pts, unsigned long long seed,
+                                                    int max_rounds, float* __restrict__ part_a, float* __restrict__ part_b,
+                                                    float* __restrict__ plane_out, int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) float sp[];      // N*3 points
+    __shared__ int wave_cnt[4];
+    __shared__ float sel[4];
+    __shared__ int sel_flag, wsum[4];
+    const int cloud = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float* P = pts + (long)cloud * N * 3;
+    for (int i = tid; i < N * 3; i += 256) sp[i] = P[i];
+    if (tid == 0) sel_flag = -1;
+    __syncthreads();
+    const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
+    int chosen_side = 0;   // +1: the "under" (check > 0) side has `target` points, -1: the other side
+    float a = 0, b = 0, c = 0, d = 0;
+    for (int round = 0; round < max_rounds; ++round) {
+        // wave-uniform candidate plane
+        const uint4 r0 = philox4x32_10(make_uint4((uint32_t)cloud, (uint32_t)round, (uint32_t)wid, 0u), key);
+        const uint4 r1 = philox4x32_10(make_uint4((uint32_t)cloud, (uint32_t)round, (uint32_t)wid, 1u), key);
+        const uint4 r2 = philox4x32_10(make_uint4((uint32_t)cloud, (uint32_t)round, (uint32_t)wid, 2u), key);
+        auto u01 = [](uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); };
+        const float p0x = u01(r0.x), p0y = u01(r0.y), p0z = u01(r0.z);
+        const float ux = u01(r1.x) - p0x, uy = u01(r1.y) - p0y, uz = u01(r1.z) - p0z;
+        const float vx = u01(r2.x) - p0x, vy = u01(r2.y) - p0y, vz = u01(r2.z) - p0z;
+        const float nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
+        const float bias = nx * p0x + ny * p0y + nz * p0z;         // HyperPlane(cp, np.dot(cp, points[0]))
+        int cnt = 0;
+        for (int i = lane; i < N; i += 64) cnt += (sp[i * 3] * nx + sp[i * 3 + 1] * ny + sp[i * 3 + 2] * nz + bias) > 0.f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+        if (lane == 0) wave_cnt[wid] = cnt;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 0; w < 4 && sel_flag < 0; ++w)
+                if (wave_cnt[w] == target || N - wave_cnt[w] == target) sel_flag = w;
+        }
+        __syncthreads();
+        const int win = sel_flag;
+        if (win >= 0) {
+            if (wid == win && lane == 0) {
+                sel[0] = nx; sel[1] = ny; sel[2] = nz; sel[3] = bias;
+            }
+            __syncthreads();
+            a = sel[0]; b = sel[1]; c = sel[2]; d = sel[3];
+            chosen_side = (wave_cnt[win] == target) ? 1 : -1;      // the reference tests the "under" side first
+            break;
+        }
+        __syncthreads();
+    }
+    if (chosen_side == 0) {
+        if (tid == 0) status[cloud] = 1;       // no plane found within max_rounds
+        return;
+    }
+    if (tid == 0) {
+        status[cloud] = 0;
+        plane_out[cloud * 4 + 0] = a; plane_out[cloud * 4 + 1] = b; plane_out[cloud * 4 + 2] = c; plane_out[cloud * 4 + 3] = d;
+    }
+    // order-preserving compaction: chunk of 256 points per iteration, exclusive scan of the membership flags
+    float* A = part_a + (long)cloud * target * 3;
+    float* Bp = part_b + (long)cloud * (N - target) * 3;
+    int base_a = 0;
+    for (int i0 = 0; i0 < N; i0 += 256) {
+        const int i = i0 + tid;
+        bool under = false, valid = i < N;
+        if (valid) under = (sp[i * 3] * a + sp[i * 3 + 1] * b + sp[i * 3 + 2] * c + d) > 0.f;
+        const bool in_a = valid && (chosen_side > 0 ? under : !under);
+        const unsigned long long m = __ballot(in_a);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wid] = __popcll(m);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < 4; ++w) {
+            if (w < wid) woff += wsum[w];
+            tot += wsum[w];
+        }
+        if (valid) {
+            const int pa = base_a + woff + before;
+            const int pb = i - pa;                                  // points before i that are not in A
+            float* o = in_a ? A + (long)pa * 3 : Bp + (long)pb * 3;
+            o[0] = sp[i * 3]; o[1] = sp[i * 3 + 1]; o[2] = sp[i * 3 + 2];
+        }
+        base_a += tot;
+        __syncthreads();
+    }
+}
+
 // KLD = 0.5 * sum(exp(v) + mu^2 - 1 - v) / B with v = the encoder's exp(logvar) output
 // single block: ordered double accumulation; also writes the two gradients scaled by `gscale`
 __global__ __launch_bounds__(256) void kld_kernel(long n, float inv_b, const float* __restrict__ v, const float* __restrict__ mu,
@@ -132,6 +228,19 @@ HP_API int hp_sample_points(long total, float coef, unsigned long long seed, uns
     if (total == 0) return 0;
     hipLaunchKernelGGL(sample_points_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, total, coef, seed, offset,
                        out);
+    HP_RETURN_LAST_ERROR();
+}
+
+// Random-plane split of B clouds (datasets/utils/dataset_generator.py:26-39): part_a (B,target,3) = the side with
+// exactly `target` points, part_b (B,N-target,3) the rest, both in the cloud's original point order; plane (B,4) =
+// (normal, bias) of the accepted plane; status (B) = 0, or 1 if no plane was accepted within max_rounds*4 draws.
+HP_API int hp_slice_clouds(int B, int N, int target, const float* pts, unsigned long long seed, int max_rounds, float* part_a,
+                           float* part_b, float* plane, int* status, hipStream_t stream) {
+    HP_CHECK_ARG(B >= 0 && N > 0 && target > 0 && target < N && N <= kSliceMaxPts && max_rounds > 0);
+    if (B == 0) return 0;
+    HP_CHECK_ARG(pts && part_a && part_b && plane && status);
+    hipLaunchKernelGGL(slice_kernel, dim3(B), dim3(256), (size_t)N * 3 * sizeof(float), stream, N, target, pts, seed, max_rounds,
+                       part_a, part_b, plane, status);
     HP_RETURN_LAST_ERROR();
 }
 

@@ -280,6 +280,24 @@ def sample_points(B, N, coef, seed, offset, device):
     return out
 
 
+def slice_clouds(points, target=1024, seed=0, max_rounds=100000):
+    """Random-plane slicer (datasets/utils/dataset_generator.py:26-39) for a batch of clouds on the device.
+    points (B,N,3) -> (part_with_target_points (B,target,3), rest (B,N-target,3), plane (B,4))."""
+    points = points.contiguous()
+    check_input(points, "points")
+    B, N = points.size(0), points.size(1)
+    dev = points.device
+    a = torch.empty((B, target, 3), dtype=torch.float32, device=dev)
+    b = torch.empty((B, N - target, 3), dtype=torch.float32, device=dev)
+    plane = torch.empty((B, 4), dtype=torch.float32, device=dev)
+    status = torch.empty((B,), dtype=torch.int32, device=dev)
+    call("hp_slice_clouds", B, N, target, points, ctypes.c_ulonglong(seed & (2 ** 64 - 1)), max_rounds, a, b, plane, status,
+         current_stream(dev))
+    if int(status.max().item()) != 0:     # data preparation, not the training step: a host sync is fine here
+        raise HipExtensionError(f"no plane with a {target}-point side found for {int((status != 0).sum())} cloud(s)")
+    return a, b, plane
+
+
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     """In-place fused Adam over flat fp32 tensors (torch.optim.Adam semantics, wd=0, amsgrad=False)."""
     for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):

@@ -214,6 +214,11 @@ int hp_target_backward(int B, int N, int n_hidden, const int* channels, const fl
 /* Decoder input points (utils/points.py:8-36 distribution) for total = B*N points, Philox(seed, offset). */
 int hp_sample_points(long total, float coef, unsigned long long seed, unsigned long long offset, float* out,
                      hpStream_t stream);
+/* Random-plane slicer (datasets/utils/dataset_generator.py:26-39) for B clouds: part_a (B,target,3) is the side of an
+ * accepted random plane that holds exactly `target` points, part_b (B,N-target,3) the rest, both in original order;
+ * plane (B,4) = normal + bias of the accepted plane; status (B) int: 0 ok, 1 none accepted in max_rounds*4 draws. */
+int hp_slice_clouds(int B, int N, int target, const float* pts, unsigned long long seed, int max_rounds, float* part_a,
+                    float* part_b, float* plane, int* status, hpStream_t stream);
 /* KLD term of core/epoch_loops.py:29-30 and its gradients */
 int hp_kld_forward(long n, int batch, const float* explv, const float* mu, float* out, hpStream_t stream);
 int hp_kld_backward(long n, int batch, const float* explv, const float* mu, const float* grad_out, float* grad_explv,
