@@ -307,6 +307,29 @@ __global__ __launch_bounds__(WGM* WGN * 64, (BM == 128 && BN == 128) ? 4 : 1) vo
     }
 }
 
+// sum_s w[s * stride] in slab order; the loads of 16 slabs are issued together (a serial chain of 64 dependent
+// round trips to HBM costs 30 us on its own).
+__device__ __forceinline__ float slab_sum(const float* __restrict__ w, long stride, int n) {
+    float v = 0.f;
+    int s = 0;
+    for (; s + 16 <= n; s += 16) {
+        float t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = w[(long)(s + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v += t[u];
+    }
+    for (; s + 4 <= n; s += 4) {
+        float t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = w[(long)(s + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v += t[u];
+    }
+    for (; s < n; ++s) v += w[(long)s * stride];
+    return v;
+}
+
 // C = epi(sum_s ws[z][s]) in split order
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams p) {
     const long mn = (long)p.M * p.N;
@@ -317,8 +340,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams p) {
     float* C = p.C + (long)z * p.sCz;
     for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < mn; t += (long)gridDim.x * 256) {
         const float* w = p.ws + (long)z * p.ksplit * mn + t;
-        float v = 0.f;
-        for (int s = 0; s < p.ksplit; ++s) v += w[(long)s * mn];
+        const float v0 = slab_sum(w, mn, p.ksplit);
+        float v = v0;
         const int row = (int)(t / p.N), col = (int)(t - (long)row * p.N);
         if (bias) v += bias[col];
         if (add) v += add[(long)row * p.ldadd + col];
@@ -329,9 +352,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams p) {
     if ((p.flags & HP_GEMM_ROWSUM) && blockIdx.x == 0) {
         for (int i = threadIdx.x; i < p.M; i += 256) {
             const float* w = p.ws + p.ws_rsum_off + (long)z * p.ksplit * p.M + i;
-            float s = 0.f;
-            for (int q = 0; q < p.ksplit; ++q) s += w[(long)q * p.M];
-            p.rsum[(long)z * p.sRsumz + i] = s;
+            p.rsum[(long)z * p.sRsumz + i] = slab_sum(w, p.M, p.ksplit);
         }
     }
 }

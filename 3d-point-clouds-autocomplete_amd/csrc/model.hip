@@ -186,26 +186,45 @@ __global__ __launch_bounds__(256) void gather_rows3_kernel(const float* __restri
 //   dW5[c,k]       = sum_b dg[b,c] * h4c[(b,c),k]
 //   d4[(b,c),k]    = dg[b,c] * W5[c,k] * (h4c[(b,c),k] > 0)
 //   db5[c]         = sum_b dg[b,c]
+// One workgroup per channel c; K % 4 == 0.  Thread (q = tid & 127, g = tid >> 7) owns 4 consecutive k and the
+// clouds b = g, g + 2, ...; the two b-halves are combined through LDS in a fixed order.
 __global__ __launch_bounds__(256) void enc_l5_bwd_kernel(int B, int C, int K, const float* __restrict__ dg,
                                                          const float* __restrict__ W5, const float* __restrict__ h4c,
                                                          float* __restrict__ dW5, float* __restrict__ d4, float* __restrict__ db5) {
+    __shared__ float4 red[128];
     const int c = blockIdx.x;
+    const int q = threadIdx.x & 127, g = threadIdx.x >> 7;
     if (threadIdx.x == 0) {
         float s = 0.f;
         for (int b = 0; b < B; ++b) s += dg[(long)b * C + c];
         db5[c] = s;
     }
-    for (int k = threadIdx.x; k < K; k += 256) {
-        const float w = W5[(long)c * K + k];
-        float s = 0.f;
-        for (int b = 0; b < B; ++b) {
-            const float gbc = dg[(long)b * C + c];
+    for (int k = q * 4; k < K; k += 512) {
+        const float4 w = *reinterpret_cast<const float4*>(W5 + (long)c * K + k);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int b = g; b < B; b += 2) {
             const long row = (long)b * C + c;
-            const float hv = h4c[row * K + k];
-            s = __builtin_fmaf(gbc, hv, s);
-            d4[row * K + k] = hv > 0.f ? gbc * w : 0.f;
+            const float gbc = dg[row];
+            const float4 hv = *reinterpret_cast<const float4*>(h4c + row * K + k);
+            s.x = __builtin_fmaf(gbc, hv.x, s.x);
+            s.y = __builtin_fmaf(gbc, hv.y, s.y);
+            s.z = __builtin_fmaf(gbc, hv.z, s.z);
+            s.w = __builtin_fmaf(gbc, hv.w, s.w);
+            float4 o;
+            o.x = hv.x > 0.f ? gbc * w.x : 0.f;
+            o.y = hv.y > 0.f ? gbc * w.y : 0.f;
+            o.z = hv.z > 0.f ? gbc * w.z : 0.f;
+            o.w = hv.w > 0.f ? gbc * w.w : 0.f;
+            *reinterpret_cast<float4*>(d4 + row * K + k) = o;
         }
-        dW5[(long)c * K + k] = s;
+        if (g == 1) red[q] = s;
+        __syncthreads();
+        if (g == 0) {
+            const float4 t = red[q];
+            *reinterpret_cast<float4*>(dW5 + (long)c * K + k) = make_float4(s.x + t.x, s.y + t.y, s.z + t.z, s.w + t.w);
+        }
+        __syncthreads();
     }
 }
 

@@ -306,7 +306,7 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
          float(grad_scale), current_stream(p.device))
 
 
-def gemm(A, B, bias=None, relu=False, trans_a=False, trans_b=True, mask=None, add=None, ksplit=1, rowsum=False):
+def gemm(A, B, bias=None, relu=False, trans_a=False, trans_b=True, mask=None, add=None, ksplit=1, rowsum=False, out=None):
     """Thin test hook over hp_gemm_f32 for 2-D / 3-D (batched) fp32 tensors:
     C = epi(op(A) @ op(B)); trans_b=True means B is stored (N, K) like an nn.Linear weight."""
     class _Desc(ctypes.Structure):
@@ -325,7 +325,13 @@ def gemm(A, B, bias=None, relu=False, trans_a=False, trans_b=True, mask=None, ad
     batch = A3.size(0)
     M, K = (A3.size(2), A3.size(1)) if trans_a else (A3.size(1), A3.size(2))
     N = B3.size(1) if trans_b else B3.size(2)
-    C = torch.empty((batch, M, N), dtype=torch.float32, device=A.device)
+    if out is not None:
+        check_input(out, "out")
+        C = out if out.dim() == 3 else out.unsqueeze(0)
+        if tuple(C.shape) != (batch, M, N):
+            raise RuntimeError(f"out must have shape {(batch, M, N)}")
+    else:
+        C = torch.empty((batch, M, N), dtype=torch.float32, device=A.device)
     d = _Desc()
     d.A, d.B, d.C = A3.data_ptr(), B3.data_ptr(), C.data_ptr()
     d.sAz = A3.stride(0)

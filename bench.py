@@ -75,7 +75,8 @@ def roofline_dominant_kernel(batch, n_half):
     a = torch.randn(m, 512, device="cuda")
     w = torch.randn(512, 512, device="cuda") * 0.05
     b = torch.zeros(512, device="cuda")
-    ms = event_time_ms(lambda: gemm(a, w, bias=b), iters=20, warm=3)
+    c = torch.empty(m, 512, device="cuda")
+    ms = event_time_ms(lambda: gemm(a, w, bias=b, out=c), iters=20, warm=3)
     flops = 2.0 * m * 512 * 512
     achieved = flops / (ms * 1e-3) / 1e12
     traffic = None
