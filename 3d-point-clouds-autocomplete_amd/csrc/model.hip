@@ -13,9 +13,9 @@
 //
 // Encoder backward uses the exact critical-point sparsity of a PointNet:
 // d/d h5[n,c] is non-zero only at n = argmax_n h5[n,c]; all layers are pointwise, so only the
-// B*512 (cloud, channel) critical rows carry gradient.  Those rows are gathered, their activations
-// recomputed (bit-identical: the GEMM's k-order does not depend on the row), and the backward
-// GEMMs run over B*512 rows instead of B*Np — no activation tensor is kept from the forward.
+// B*512 (cloud, channel) critical rows carry gradient.  Those rows' activations are copied out of the
+// forward's workspace (or, if the caller dropped it, recomputed — bit-identical: the GEMM's k-order does
+// not depend on the row), and the backward GEMMs run over B*512 rows instead of B*Np.
 #include "hp_common.h"
 #include "hp_gemm.h"
 #include "hp_model.h"
@@ -182,6 +182,30 @@ __global__ __launch_bounds__(256) void gather_rows3_kernel(const float* __restri
     xc[t * 3 + 2] = s[2];
 }
 
+// One workgroup per critical row t = (b, c): copies the row's x (3), h1 (64), h2 (128), h3 (256), h4 (512) out of
+// the forward's per-point activation arrays (source row b*Np + arg[t]) with 16-byte accesses.
+__global__ __launch_bounds__(256) void gather_critical_kernel(int Np, const int* __restrict__ arg, const float* __restrict__ x,
+                                                              const float* __restrict__ h1, const float* __restrict__ h2,
+                                                              const float* __restrict__ h3, const float* __restrict__ h4,
+                                                              float* __restrict__ xc, float* __restrict__ c1,
+                                                              float* __restrict__ c2, float* __restrict__ c3,
+                                                              float* __restrict__ c4) {
+    const long t = blockIdx.x;
+    const long src = (t >> 9) * Np + arg[t];
+    const int i = threadIdx.x;
+    if (i < 16) {
+        reinterpret_cast<float4*>(c1 + t * 64)[i] = reinterpret_cast<const float4*>(h1 + src * 64)[i];
+    } else if (i < 48) {
+        reinterpret_cast<float4*>(c2 + t * 128)[i - 16] = reinterpret_cast<const float4*>(h2 + src * 128)[i - 16];
+    } else if (i < 112) {
+        reinterpret_cast<float4*>(c3 + t * 256)[i - 48] = reinterpret_cast<const float4*>(h3 + src * 256)[i - 48];
+    } else if (i < 240) {
+        reinterpret_cast<float4*>(c4 + t * 512)[i - 112] = reinterpret_cast<const float4*>(h4 + src * 512)[i - 112];
+    } else if (i < 243) {
+        xc[t * 3 + (i - 240)] = x[src * 3 + (i - 240)];
+    }
+}
+
 // Layer-5 backward on the critical rows (one-hot upstream):
 //   dW5[c,k]       = sum_b dg[b,c] * h4c[(b,c),k]
 //   d4[(b,c),k]    = dg[b,c] * W5[c,k] * (h4c[(b,c),k] > 0)
@@ -342,15 +366,24 @@ EncBwdWs enc_bwd_layout(float* ws, long B, long out_size) {
 }
 }  // namespace
 
-// The gradient-independent half of the encoder backward: gather the B*512 critical rows (arg-max points) and
-// recompute their activations h1..h4 into `ws` (the hp_encoder_backward workspace).  It needs only the forward's
-// arg-max, so a caller may run it EARLY on another stream, under the rest of the forward / the loss kernels, and
-// pass prepared=1 to hp_encoder_backward.
-HP_API int hp_encoder_backward_prepare(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size,
-                                       const int* argidx, float* ws, hipStream_t stream) {
-    HP_CHECK_ARG(B > 0 && Np > 0 && out_size > 0 && x && w && argidx && ws);
+// Activations h1..h4 of the B*512 critical rows (arg-max points) into `ws` (the hp_encoder_backward workspace).
+// With the forward's workspace at hand (`fwd_ws`, h1..h4 of every point still in place) they are copied out of it —
+// one pass over 3.8 KB per critical row; without it (fwd_ws == NULL: the caller dropped the 15 KB/point forward
+// workspace) they are recomputed from the gathered coordinates, the same GEMM chain on B*512 rows.
+static int enc_critical_rows(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size, const int* argidx,
+                             const float* fwd_ws, float* ws, hipStream_t stream) {
     const long Rc = (long)B * 512;
     EncBwdWs L = enc_bwd_layout(ws, B, out_size);
+    if (fwd_ws) {
+        const long R = (long)B * Np;
+        const float* h1 = fwd_ws;
+        const float* h2 = h1 + R * 64;
+        const float* h3 = h2 + R * 128;
+        const float* h4 = h3 + R * 256;
+        hipLaunchKernelGGL(gather_critical_kernel, dim3((unsigned)Rc), dim3(256), 0, stream, Np, argidx, x, h1, h2, h3, h4, L.xc,
+                           L.hc[1], L.hc[2], L.hc[3], L.hc[4]);
+        HP_RETURN_LAST_ERROR();
+    }
     Op op{stream, nullptr};
     hipLaunchKernelGGL(gather_rows3_kernel, dim3((int)cdiv(Rc, 256)), dim3(256), 0, stream, x, Np, argidx, Rc, 512, L.xc);
     const float* in = L.xc;
@@ -363,12 +396,12 @@ HP_API int hp_encoder_backward_prepare(int B, int Np, const float* x, const HpEn
 }
 
 // Gradients of every encoder parameter.  grad_out: d/d z (VAE) or d/d mu (plain); grad_mu / grad_explv:
-// direct gradients on the VAE's mu / exp(logvar) outputs (KLD term), may be NULL.  prepared != 0: `ws` already
-// holds the recomputed critical-row activations (hp_encoder_backward_prepare).
+// direct gradients on the VAE's mu / exp(logvar) outputs (KLD term), may be NULL.  fwd_ws: the workspace
+// hp_encoder_forward ran in, untouched since (NULL: recompute the critical rows' activations instead).
 HP_API int hp_encoder_backward(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size, int is_vae,
                                const float* eps, const int* argidx, const float* g, const float* f, const float* lv,
                                const float* grad_out, const float* grad_mu, const float* grad_explv,
-                               const HpEncoderGrads* gr, float* ws, int prepared, hipStream_t stream) {
+                               const HpEncoderGrads* gr, float* ws, const float* fwd_ws, hipStream_t stream) {
     HP_CHECK_ARG(B > 0 && Np > 0 && out_size > 0 && x && w && argidx && g && f && gr && ws);
     HP_CHECK_ARG(grad_out || grad_mu || grad_explv);
     HP_CHECK_ARG(!is_vae || (eps && lv));
@@ -379,7 +412,7 @@ HP_API int hp_encoder_backward(int B, int Np, const float* x, const HpEncoderWei
     float** dl = L.dl;
     float *dmu = L.dmu, *dlv = L.dlv, *tmp = L.tmp, *dfc = L.dfc, *dg = L.dg;
     Op op{stream, L.split};
-    if (!prepared) TRY(hp_encoder_backward_prepare(B, Np, x, w, out_size, argidx, ws, stream));
+    TRY(enc_critical_rows(B, Np, x, w, out_size, argidx, fwd_ws, ws, stream));
 
     // ---- heads (model/encoder.py:46-53)
     const float* dmu_p;

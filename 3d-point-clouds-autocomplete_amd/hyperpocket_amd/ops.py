@@ -65,17 +65,9 @@ def _grad_buffer(param):
     return torch.empty_like(param, memory_format=torch.contiguous_format)
 
 
-# Measured on MI355X (B=64): running the gradient-independent half of the encoder backward early on a helper stream
-# does not shorten the step (the two-stream encoder arrangement already overlaps it): 11 420 vs 11 431 clouds/s.  Off.
-EARLY_BACKWARD_PREP = False
-_HELPER_STREAMS = {}
-
-
-def _helper_stream(dev):
-    key = (dev.type, dev.index)
-    if key not in _HELPER_STREAMS:
-        _HELPER_STREAMS[key] = torch.cuda.Stream(device=dev)
-    return _HELPER_STREAMS[key]
+# The encoder backward copies the critical rows' activations out of the forward's workspace (15 KB per point, kept
+# alive by the autograd node).  False: drop the workspace after the forward and recompute those rows instead.
+KEEP_ENCODER_ACTIVATIONS = True
 
 
 def _encoder_struct(params, cls=_EncoderPtrs):
@@ -116,19 +108,7 @@ class EncoderFunction(Function):
         call("hp_encoder_forward", B, Np, x, ctypes.byref(w), out_size, int(is_vae), eps, argidx, g, f, mu, lv, z, explv,
              ws, current_stream(dev))
         ctx.is_vae, ctx.out_size = is_vae, out_size
-        ctx.prep_ws = ctx.prep_event = None
-        if EARLY_BACKWARD_PREP and any(ctx.needs_input_grad[3:]):
-            # the backward's gradient-independent half (critical-row gather + activation recompute, MFMA work) runs now
-            # on a helper stream, under the rest of the forward and the (VALU-bound) loss kernels
-            cur = torch.cuda.current_stream(dev)
-            helper = _helper_stream(dev)
-            ws_b = torch.empty((_long_fn("hp_encoder_backward_workspace_floats", B, out_size),), **f32)
-            helper.wait_stream(cur)
-            for t in (ws_b, x, argidx, *params):
-                t.record_stream(helper)
-            call("hp_encoder_backward_prepare", B, Np, x, ctypes.byref(w), out_size, argidx, ws_b,
-                 ctypes.c_void_p(helper.cuda_stream))
-            ctx.prep_ws, ctx.prep_event = ws_b, helper.record_event()
+        ctx.fwd_ws = ws if KEEP_ENCODER_ACTIVATIONS else None
         ctx.save_for_backward(x, eps, argidx, g, f, lv, *params)
         if is_vae:
             return z, mu, explv
@@ -145,17 +125,12 @@ class EncoderFunction(Function):
         else:
             gout, gmu, gexplv = grads[0].contiguous(), None, None
         out = [_grad_buffer(p) for p in params]
-        prepared = ctx.prep_ws is not None
-        if prepared:
-            ws = ctx.prep_ws
-            torch.cuda.current_stream(dev).wait_event(ctx.prep_event)
-        else:
-            ws = torch.empty((_long_fn("hp_encoder_backward_workspace_floats", B, ctx.out_size),), dtype=torch.float32,
-                             device=dev)
+        ws = torch.empty((_long_fn("hp_encoder_backward_workspace_floats", B, ctx.out_size),), dtype=torch.float32,
+                         device=dev)
         w, gr = _encoder_struct(params), _encoder_struct(out)
         call("hp_encoder_backward", B, Np, x, ctypes.byref(w), ctx.out_size, int(ctx.is_vae), eps, argidx, g, f, lv,
-             gout, gmu, gexplv, ctypes.byref(gr), ws, int(prepared), current_stream(dev))
-        ctx.prep_ws = None
+             gout, gmu, gexplv, ctypes.byref(gr), ws, ctx.fwd_ws, current_stream(dev))
+        ctx.fwd_ws = None
         return (None, None, None, *out)
 
 
@@ -306,17 +281,19 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
          float(grad_scale), current_stream(p.device))
 
 
+class _GemmDesc(ctypes.Structure):
+    _fields_ = [("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("bias", c_void_p), ("mask", c_void_p),
+                ("add", c_void_p), ("ws", c_void_p),
+                ("sAz", c_long), ("sBz", c_long), ("sCz", c_long), ("sBiasz", c_long), ("sMaskz", c_long), ("sAddz", c_long),
+                ("sAi", c_long), ("sAk", c_long), ("sBk", c_long), ("sBj", c_long),
+                ("ldc", c_int), ("ldmask", c_int), ("ldadd", c_int),
+                ("M", c_int), ("N", c_int), ("K", c_int), ("batch", c_int), ("ksplit", c_int), ("flags", c_int),
+                ("cmax", c_void_p), ("cidx", c_void_p), ("group_rows", c_int), ("rsum", c_void_p), ("sRsumz", c_long)]
+
+
 def gemm(A, B, bias=None, relu=False, trans_a=False, trans_b=True, mask=None, add=None, ksplit=1, rowsum=False, out=None):
     """Thin test hook over hp_gemm_f32 for 2-D / 3-D (batched) fp32 tensors:
     C = epi(op(A) @ op(B)); trans_b=True means B is stored (N, K) like an nn.Linear weight."""
-    class _Desc(ctypes.Structure):
-        _fields_ = [("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("bias", c_void_p), ("mask", c_void_p),
-                    ("add", c_void_p), ("ws", c_void_p),
-                    ("sAz", c_long), ("sBz", c_long), ("sCz", c_long), ("sBiasz", c_long), ("sMaskz", c_long), ("sAddz", c_long),
-                    ("sAi", c_long), ("sAk", c_long), ("sBk", c_long), ("sBj", c_long),
-                    ("ldc", c_int), ("ldmask", c_int), ("ldadd", c_int),
-                    ("M", c_int), ("N", c_int), ("K", c_int), ("batch", c_int), ("ksplit", c_int), ("flags", c_int),
-                    ("cmax", c_void_p), ("cidx", c_void_p), ("group_rows", c_int), ("rsum", c_void_p), ("sRsumz", c_long)]
     batched = A.dim() == 3
     A3 = A if batched else A.unsqueeze(0)
     B3 = B if B.dim() == 3 else B.unsqueeze(0)
@@ -332,7 +309,7 @@ def gemm(A, B, bias=None, relu=False, trans_a=False, trans_b=True, mask=None, ad
             raise RuntimeError(f"out must have shape {(batch, M, N)}")
     else:
         C = torch.empty((batch, M, N), dtype=torch.float32, device=A.device)
-    d = _Desc()
+    d = _GemmDesc()
     d.A, d.B, d.C = A3.data_ptr(), B3.data_ptr(), C.data_ptr()
     d.sAz = A3.stride(0)
     d.sBz = B3.stride(0) if B3.size(0) > 1 else 0

@@ -17,6 +17,7 @@ One JSON line on rank 0; besides the contract keys it carries
 """
 import argparse
 import copy
+import gc
 import json
 import os
 import sys
@@ -51,16 +52,23 @@ def synth_batch(b, n_half, device, seed):
 
 
 def event_time_ms(fn, iters, warm=2):
-    """Average duration of fn() measured with HIP events on the stream fn launches on (torch's current stream)."""
+    """Average duration of fn() measured with HIP events on the stream fn launches on (torch's current stream).
+    The events bracket back-to-back launches, so a host-side pause longer than the queued work would be counted as
+    kernel time: Python's cyclic collector (a 30 ms gen-2 pass was observed here) is held off for the region."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(iters):
-        fn()
-    e.record()
-    torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()
+    try:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+    finally:
+        gc.enable()
     return s.elapsed_time(e) / iters
 
 

@@ -176,16 +176,14 @@ int hp_encoder_forward(int B, int Np, const float* x, const HpEncoderWeights* w,
                        const float* eps, int* argidx, float* g, float* f, float* mu, float* lv, float* z, float* explv,
                        float* ws, hpStream_t stream);
 /* Gradients of every encoder parameter (autograd of the above).  grad_out = d/dz (VAE) or d/dmu (plain);
- * grad_mu / grad_explv = direct gradients on the VAE outputs (may be NULL). */
+ * grad_mu / grad_explv = direct gradients on the VAE outputs (may be NULL).  Only the 512 arg-max points of a
+ * cloud carry gradient below the max-pool: their activations are copied out of fwd_ws (the workspace
+ * hp_encoder_forward ran in, untouched since) or, with fwd_ws = NULL, recomputed from x. */
 long hp_encoder_backward_workspace_floats(int B, int out_size);
-/* gradient-independent half (gather of the critical rows + recomputation of their activations into ws): may run
- * early, on another stream; then pass prepared = 1 below */
-int hp_encoder_backward_prepare(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size,
-                                const int* argidx, float* ws, hpStream_t stream);
 int hp_encoder_backward(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size, int is_vae,
                         const float* eps, const int* argidx, const float* g, const float* f, const float* lv,
                         const float* grad_out, const float* grad_mu, const float* grad_explv, const HpEncoderGrads* grads,
-                        float* ws, int prepared, hpStream_t stream);
+                        float* ws, const float* fwd_ws, hpStream_t stream);
 
 /* HyperNetwork.forward (model/hyper_network.py:41-43): latent (B,in) -> theta (B,theta_ld); t = saved trunk
  * activations (hp_hypernet_saved_floats floats) for the backward. */

@@ -141,6 +141,33 @@ def test_encoder_forward_backward_vs_oracle(ref):
                 grad_close(p.grad, want)
 
 
+def test_encoder_backward_gather_equals_recompute():
+    """The two sources of the critical rows' activations (copied out of the forward's workspace / recomputed from the
+    gathered coordinates) give bit-identical parameter gradients."""
+    from hyperpocket_amd import ops
+    from hyperpocket_amd.model.encoder import Encoder
+    from hyperpocket_amd.core.setup import weights_init
+    for is_vae, B, Np in [(True, 4, 1024), (False, 3, 300)]:
+        torch.manual_seed(11)
+        enc = Encoder({"output_size": 128, "use_bias": True, "relu_slope": 0.2}, is_vae=is_vae).apply(weights_init).cuda()
+        x = (torch.rand(B, Np, 3, device="cuda") - 0.5).transpose(1, 2)
+        eps = torch.randn(B, 128, device="cuda")
+        grads = []
+        for keep in (True, False):
+            ops.KEEP_ENCODER_ACTIVATIONS = keep
+            try:
+                for p in enc.parameters():
+                    p.grad = None
+                out = enc(x, eps) if is_vae else (enc(x),)
+                sum((o * (i + 1.5)).sum() for i, o in enumerate(out)).backward()
+            finally:
+                ops.KEEP_ENCODER_ACTIVATIONS = True
+            grads.append({k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None})
+        assert grads[0].keys() == grads[1].keys()
+        for k in grads[0]:
+            assert torch.equal(grads[0][k], grads[1][k]), k
+
+
 def test_hypernet_forward_backward_vs_oracle(ref):
     from hyperpocket_amd.model.hyper_network import HyperNetwork
     from hyperpocket_amd.core.setup import weights_init
