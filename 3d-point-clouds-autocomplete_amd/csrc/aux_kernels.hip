@@ -259,6 +259,41 @@ HP_API int hp_kld_backward(long n, int batch, const float* explv, const float* m
     HP_RETURN_LAST_ERROR();
 }
 
+// The step's scalar loss terms in one launch (core/epoch_loops.py:26-31 plus the optional EMD term):
+//   out[0] = loss_r = c_cd * cd ; out[1] = loss_kld = kld ; out[2] = loss_emd = c_emd * sum_b cost[b] (cloud order) ;
+//   out[3] = loss_all = out[0] + out[1] + out[2].   kld / cost may be NULL (term absent: 0).
+namespace {
+__global__ __launch_bounds__(64) void step_losses_kernel(int b, const float* __restrict__ cd, const float* __restrict__ kld,
+                                                         const float* __restrict__ cost, float c_cd, float c_emd,
+                                                         float* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    float e = 0.f;
+    if (cost) {
+        int i = 0;
+        for (; i + 8 <= b; i += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = cost[i + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) e += t[u];
+        }
+        for (; i < b; ++i) e += cost[i];
+    }
+    const float lr = c_cd * cd[0], lk = kld ? kld[0] : 0.f, le = c_emd * e;
+    out[0] = lr;
+    out[1] = lk;
+    out[2] = le;
+    out[3] = (lr + lk) + le;
+}
+}  // namespace
+
+HP_API int hp_step_losses(int b, const float* cd, const float* kld, const float* cost, float c_cd, float c_emd, float* out,
+                          hipStream_t stream) {
+    HP_CHECK_ARG(b >= 0 && cd && out);
+    hipLaunchKernelGGL(step_losses_kernel, dim3(1), dim3(64), 0, stream, b, cd, kld, cost, c_cd, c_emd, out);
+    HP_RETURN_LAST_ERROR();
+}
+
 // One Adam step over a contiguous run of n parameters (step = 1-based step count).
 // grad_scale multiplies the gradient first (1 for the reference's semantics).
 HP_API int hp_adam_step(long n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2, float eps,

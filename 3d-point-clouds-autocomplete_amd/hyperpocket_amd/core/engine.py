@@ -1,17 +1,19 @@
 """TrainEngine — the build's fast counterpart of one iteration of core/epoch_loops.py:14-39
 (zero_grad -> forward -> 0.05*Chamfer + KLD/B [+ EMD] -> backward -> [grad all-reduce] -> Adam),
-for callers that own the whole step (bench.py, the DP launcher).  It drives the same FullModel /
-ChamferLoss / match_cost objects as the drop-in path; what it adds is the flat parameter/gradient
-layout (parallel.py), the overlapped RCCL all-reduce and the fused HIP Adam — and it never
-synchronises with the host (the reference does three `.item()` syncs per step, epoch_loops.py:32-36).
+for callers that own the whole step (bench.py, the DP launcher).  It drives the same FullModel as
+the drop-in path and the same loss kernels as ChamferLoss / match_cost (called directly: each yields
+its gradient with its value); what it adds is the flat parameter/gradient layout (parallel.py), the
+overlapped RCCL all-reduce and the fused HIP Adam — and it never synchronises with the host (the
+reference does three `.item()` syncs per step, epoch_loops.py:32-36).
 """
+import ctypes
+
 import torch
 import torch.distributed as dist
 
 from .. import ops
-from ..losses.champfer_loss import ChamferLoss
+from .._lib import call, check_input, current_stream, load_library
 from ..parallel import FlatParameters, GradientReducer
-from ..utils.pytorch_structural_losses.match_cost import match_cost
 
 
 class TrainEngine:
@@ -27,7 +29,7 @@ class TrainEngine:
         self.steps = 0
         self._heads_pending = False
         model._pre_hypernet_hook = self.finish_pending     # FullModel.forward calls it right before the hypernetwork
-        self.chamfer = ChamferLoss()
+        self._consts = {}
         if self.world > 1:
             # replicas start from rank 0's weights
             dist.broadcast(self.flat.flat, src=0, group=process_group)
@@ -48,41 +50,12 @@ class TrainEngine:
         rec, logvar, mu = model(existing.view(existing.shape), None if missing is None else missing.view(missing.shape),
                                 list(gt.shape), epoch, device, points=points, eps=eps_noise)
         rec_n3 = rec.permute(0, 2, 1)
-        side = None
-        if self.emd_coef:
-            # Chamfer (VALU-bound, ~0.3 ms) and the EMD sweeps (2 waves/SIMD, VALU pipe ~60 % busy) are independent
-            # consumers of the reconstruction: Chamfer goes to a side stream and fills the EMD's idle issue slots
-            from ..model.full_model import _side_stream
-            cur = torch.cuda.current_stream(device)
-            side = _side_stream(model, device)
-            side.wait_stream(cur)
-            rec.record_stream(side)
-            with torch.cuda.stream(side):
-                loss_r = self.loss_coef * self.chamfer(gt, rec_n3)
-        else:
-            loss_r = self.loss_coef * self.chamfer(gt, rec_n3)
-        out = {}
-        extra = []
-        if model.mode.has_generativity():
-            kld = ops.kld_loss(logvar, mu, batch=gt.size(0) * self.world)
-            extra.append(kld)
-            out["loss_kld"] = kld.detach()
-        if self.emd_coef:
-            emd = self.emd_coef * (match_cost(gt.contiguous(), rec_n3.contiguous()) / float(gt.size(1))).sum()
-            extra.append(emd)
-            out["loss_emd"] = emd.detach()
-            cur.wait_stream(side)
-            loss_r.record_stream(cur)
-        loss_all = loss_r
-        for t in extra:
-            loss_all = loss_all + t
-        out["loss_r"] = loss_r.detach()
-        out["loss_all"] = loss_all.detach()
+        roots, root_grads, out = self._losses_and_gradients(gt, rec_n3, logvar, mu)
         if self.world > 1:
             # the hypernetwork's gradients (90 % of the bytes) are complete once its backward has been
             # enqueued; ship them while the encoders' backward still runs
             self._install_overlap_hook()
-        loss_all.backward()
+        torch.autograd.backward(roots, root_grads)
         self.steps += 1
         # Exchange + update per bucket.  Trunk and encoders (17 MB) are reduced and updated now; the hypernetwork heads
         # (156 MB, 90 % of the bytes) are only needed again in the NEXT step's hypernetwork forward, which comes after
@@ -97,6 +70,86 @@ class TrainEngine:
         else:
             self._adam(0)
         return out
+
+    def _losses_and_gradients(self, gt, rec_n3, logvar, mu):
+        """loss_all = loss_coef*Chamfer(gt, rec) + KLD/B [+ emd_coef*sum_b EMD_b/N] (core/epoch_loops.py:26-31) and its
+        gradients w.r.t. the model outputs, straight from the fused kernels: every loss kernel here produces its
+        gradient alongside its value, so the autograd graph starts at the model outputs (no loss nodes, no scalar glue
+        kernels between the loss and the first backward GEMM).  Returns (roots, their gradients, the loss terms)."""
+        model = self.model
+        dev = gt.device
+        B, N = gt.size(0), gt.size(1)
+        f32 = dict(dtype=torch.float32, device=dev)
+        lib = load_library()
+        gt_c, rec_c = gt.contiguous(), rec_n3.contiguous()
+        check_input(gt_c, "gt")
+        check_input(rec_c, "reconstruction")
+        if gt_c.shape != rec_c.shape or gt_c.size(2) != 3:
+            raise RuntimeError(f"TrainEngine: reconstruction {tuple(rec_c.shape)} vs gt {tuple(gt_c.shape)}")
+        has_kld = model.mode.has_generativity()
+        if dev not in self._consts:
+            self._consts[dev] = (torch.full((), float(self.loss_coef), **f32), torch.ones((), **f32))
+        c_cd, one = self._consts[dev]
+        cur = torch.cuda.current_stream(dev)
+        side = None
+        if self.emd_coef:
+            # Chamfer / KLD (VALU-bound, ~0.15 ms) and the EMD sweeps (2 waves/SIMD, VALU pipe ~60 % busy) are
+            # independent consumers of the model outputs: the small ones go to a side stream and fill the EMD's idle
+            # issue slots
+            from ..model.full_model import _side_stream
+            side = _side_stream(model, dev)
+            side.wait_stream(cur)
+            for t in (gt_c, rec_c, logvar, mu):
+                if t is not None:
+                    t.record_stream(side)
+        with torch.cuda.stream(side if side is not None else cur):
+            st = current_stream(dev)
+            dist1, dist2 = torch.empty((B, N), **f32), torch.empty((B, N), **f32)
+            idx1 = torch.empty((B, N), dtype=torch.int32, device=dev)
+            idx2 = torch.empty((B, N), dtype=torch.int32, device=dev)
+            part = torch.empty((lib.hp_chamfer_workspace_floats(B, N, N),), **f32)
+            cd = torch.empty((), **f32)
+            g_rec = torch.empty_like(rec_c)
+            # ChamferLoss()(gt, reconstruction): losses/champfer_loss.py:11-17 with preds = gt (core/epoch_loops.py:26)
+            call("hp_chamfer_forward", B, N, gt_c, N, rec_c, dist1, idx1, dist2, idx2, part, cd, st)
+            call("hp_chamfer_backward", B, N, gt_c, N, rec_c, idx1, idx2, c_cd, None, g_rec, st)
+            kld = g_lv = g_mu = None
+            if has_kld:
+                lv_c, mu_c = logvar.contiguous(), mu.contiguous()
+                kld = torch.empty((), **f32)
+                g_lv, g_mu = torch.empty_like(lv_c), torch.empty_like(mu_c)
+                n_el, batch = ctypes.c_long(mu_c.numel()), B * self.world
+                call("hp_kld_forward", n_el, batch, lv_c, mu_c, kld, st)
+                call("hp_kld_backward", n_el, batch, lv_c, mu_c, one, g_lv, g_mu, st)
+        cost = None
+        c_emd = 0.0
+        if self.emd_coef:
+            c_emd = float(self.emd_coef) / float(N)
+            lib.hp_emd_partials_floats.restype = ctypes.c_long
+            temp = torch.empty((B, 4 * N), **f32)
+            ws = torch.empty((max(1, lib.hp_approxmatch_workspace_floats(B, N, N)),), **f32)
+            epart = torch.empty((max(1, lib.hp_emd_partials_floats(B, N, N)),), **f32)
+            cost = torch.empty((B,), **f32)
+            g_emd = torch.empty_like(rec_c)
+            # match_cost(gt, reconstruction): cost and d cost / d reconstruction from the same sweeps
+            call("hp_emd_forward", B, N, N, gt_c, rec_c, temp, ws, epart, cost, None, g_emd, current_stream(dev))
+            cur.wait_stream(side)
+            for t in (cd, g_rec, kld, g_lv, g_mu):
+                if t is not None:
+                    t.record_stream(cur)
+            g_rec = torch.add(g_rec, g_emd, alpha=c_emd)
+        terms = torch.empty((4,), **f32)
+        call("hp_step_losses", B, cd, kld, cost, float(self.loss_coef), c_emd, terms, current_stream(dev))
+        out = {"loss_r": terms[0], "loss_all": terms[3]}
+        if has_kld:
+            out["loss_kld"] = terms[1]
+        if self.emd_coef:
+            out["loss_emd"] = terms[2]
+        roots, grads = [rec_n3], [g_rec]
+        if has_kld:
+            roots += [logvar, mu]
+            grads += [g_lv.view_as(logvar), g_mu.view_as(mu)]
+        return roots, grads, out
 
     def _adam(self, bucket):
         lo, hi = self.flat.buckets[bucket]

@@ -221,6 +221,12 @@ int hp_slice_clouds(int B, int N, int target, const float* pts, unsigned long lo
 int hp_kld_forward(long n, int batch, const float* explv, const float* mu, float* out, hpStream_t stream);
 int hp_kld_backward(long n, int batch, const float* explv, const float* mu, const float* grad_out, float* grad_explv,
                     float* grad_mu, hpStream_t stream);
+/* TrainEngine glue — the step's scalar loss terms in one launch (core/epoch_loops.py:26-31 + the optional EMD term):
+ * out[0] = loss_r = c_cd*cd[0], out[1] = loss_kld = kld[0], out[2] = loss_emd = c_emd * sum_b cost[b], out[3] = their sum.
+ * kld / cost may be NULL (term absent). */
+int hp_step_losses(int b, const float* cd, const float* kld, const float* cost, float c_cd, float c_emd, float* out /* 4 */,
+                   hpStream_t stream);
+
 /* torch.optim.Adam(lr, betas, eps, weight_decay=0, amsgrad=False) over n contiguous fp32 parameters (core/main.py:62-66) */
 int hp_adam_step(long n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2, float eps,
                  int step, float grad_scale, hpStream_t stream);

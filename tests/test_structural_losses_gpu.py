@@ -78,6 +78,48 @@ def test_nndistancegrad_vs_oracle(backend, oracle_lib):
     np.testing.assert_allclose(g2.cpu().numpy(), o2, atol=1e-5, rtol=1e-5)
 
 
+def test_nndistancegrad_clustered_multi_tile_and_deterministic(backend, oracle_lib):
+    """Many sources choosing the same few targets (the contended case early in training), more targets than one
+    2048-point gradient tile, and bit-identical results run to run (fixed-point LDS accumulation)."""
+    r = np.random.RandomState(17)
+    a = (r.rand(2, 3000, 3).astype(np.float32) - 0.5)
+    c = (r.rand(2, 5000, 3).astype(np.float32) - 0.5) * 3.0
+    c[:, :4990] += 5.0                      # only 10 points of c are anywhere near a
+    A, C = _dev(a), _dev(c)
+    d1, i1, d2, i2 = backend.NNDistance(A, C)
+    assert len(np.unique(i1.cpu().numpy())) <= 20
+    gd1, gd2 = r.randn(2, 3000).astype(np.float32), r.randn(2, 5000).astype(np.float32)
+    g1, g2 = backend.NNDistanceGrad(A, C, i1, i2, _dev(gd1), _dev(gd2))
+    j1, j2 = i1.cpu().numpy(), i2.cpu().numpy()
+    o1, o2 = oracle_lib.nndistancegrad(a, c, gd1, j1, gd2, j2)
+    # the oracle accumulates thousands of O(10) terms sequentially in fp32 (as the reference's atomicAdd does, in some
+    # order): loose against it, tight against the same sums in float64
+    np.testing.assert_allclose(g1.cpu().numpy(), o1, atol=1e-3, rtol=1e-4)
+    np.testing.assert_allclose(g2.cpu().numpy(), o2, atol=1e-3, rtol=1e-4)
+    t1, t2 = np.zeros(a.shape), np.zeros(c.shape)
+    for b in range(2):
+        da = 2.0 * gd1[b, :, None].astype(np.float64) * (a[b].astype(np.float64) - c[b][j1[b]])
+        dc = 2.0 * gd2[b, :, None].astype(np.float64) * (c[b].astype(np.float64) - a[b][j2[b]])
+        t1[b] += da
+        np.add.at(t2[b], j1[b], -da)
+        t2[b] += dc
+        np.add.at(t1[b], j2[b], -dc)
+    np.testing.assert_allclose(g1.cpu().numpy(), t1, atol=2e-5, rtol=2e-6)
+    np.testing.assert_allclose(g2.cpu().numpy(), t2, atol=2e-5, rtol=2e-6)
+    for _ in range(3):
+        h1, h2 = backend.NNDistanceGrad(A, C, i1, i2, _dev(gd1), _dev(gd2))
+        assert torch.equal(h1, g1) and torch.equal(h2, g2)
+
+
+def test_nndistancegrad_empty_side(backend):
+    A = torch.rand(2, 5, 3, device="cuda")
+    C = torch.empty(2, 0, 3, device="cuda")
+    i1 = torch.zeros(2, 5, dtype=torch.int32, device="cuda")
+    i2 = torch.zeros(2, 0, dtype=torch.int32, device="cuda")
+    g1, g2 = backend.NNDistanceGrad(A, C, i1, i2, torch.ones(2, 5, device="cuda"), torch.ones(2, 0, device="cuda"))
+    assert g1.shape == (2, 5, 3) and g2.shape == (2, 0, 3) and float(g1.abs().sum()) == 0.0
+
+
 def test_nn_distance_autograd_function(oracle_lib):
     from hyperpocket_amd.utils.pytorch_structural_losses.nn_distance import nn_distance
     a, c = _clouds(13, 2, 100, 90)
