@@ -11,7 +11,8 @@
 //   C[z](i,j) = epi( sum_k A[z](i,k) * B[z](k,j) ),  z = 0..batch-1
 //   A(i,k) at A + z*sAz + i*sAi + k*sAk ; B(k,j) at B + z*sBz + k*sBk + j*sBj ; C row-major, ldc.
 //   Either stride of an operand may be the unit one: a "K-contiguous" operand is fetched with
-//   16-byte loads along k, an "i/j-contiguous" one with lane-coalesced loads along i/j.  Both land
+//   16-byte loads along k (4-byte ones when its rows are not 16-byte aligned), an "i/j-contiguous"
+//   one with lane-coalesced loads along i/j.  All land
 //   in the same LDS image ([row][k], 80-byte rows: conflict-free ds_read_b128 fragment reads), so
 //   the MFMA loop is layout-agnostic.
 //   epi: + bias[j] -> ReLU -> * (mask(i,j) > 0)    (each optional; mask = stored post-ReLU
@@ -81,17 +82,26 @@ __device__ __forceinline__ float4 ld4_fast(const float* __restrict__ p, long s_k
     return make_float4(p[0], p[s_k], p[2 * s_k], p[3 * s_k]);
 }
 
-// MODE < 0: generic loaders (bounds checks, any alignment, K tails).  MODE >= 0: fast loaders — bit0: A is
-// K-contiguous, bit1: B is K-contiguous; rows/cols are clamped instead of predicated (the epilogue never stores
-// them), the k-range is a multiple of BK and K-contiguous operands are 16-byte aligned (checked on the host).
-// The generic loaders' divergent-branch scaffolding costs ~30 % of the MFMA rate (tools/exp_gemm.py).
+// MODE = am + 3*bm: the staging loader of each operand.
+//   0  i/j-contiguous: lanes run along the rows, 4 lane-coalesced loads at stride s_k
+//   1  K-contiguous and 16-byte loadable: lanes run along k, one 16-byte load
+//   2  K-contiguous, any alignment (the per-cloud weight slices of theta, row stride 19011; d theta): lanes run
+//      along k, 4 scalar loads on 4 rows — coalesced like 1 (loader 0 on such an operand touches one cache line
+//      per lane and is bound by the texture-address path), tails predicated in place
+// Loaders 0/1 clamp rows/cols instead of predicating them (the epilogue never stores them) on whole k-tiles —
+// the k-range is a multiple of BK and K-contiguous operands are 16-byte aligned (checked on the host) — and fall
+// back to the generic predicated loaders on a K tail.  The generic loaders' divergent-branch scaffolding costs
+// ~30 % of the MFMA rate (tools/exp_gemm.py).
 template <int BM, int BN, int WGM, int WGN, int BK, int MODE>
 __global__ __launch_bounds__(WGM* WGN * 64, (BM == 128 && BN == 128) ? 4 : 1) void gemm_kernel(const KParams p) {
     constexpr int NT = WGM * WGN * 64;
     constexpr int LDK = BK + 4, KQ = BK / 4;   // KQ float4 groups per staged row
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     constexpr int NA = (BM * KQ + NT - 1) / NT, NB = (BN * KQ + NT - 1) / NT;
+    constexpr int AM = MODE % 3, BMD = MODE / 3;
+    constexpr int RSTEP = NT / BK;             // loader 2: rows between a thread's consecutive elements
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
+    static_assert(NT % BK == 0, "loader 2 keeps one k per thread");
     __shared__ __attribute__((aligned(16))) float As[BM * LDK];
     __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
 
@@ -112,8 +122,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (BM == 128 && BN == 128) ? 4 : 1) vo
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WGN, wn = wid % WGN;
     const int r = lane & 31, h = lane >> 5;
-    const bool a_kc = MODE >= 0 ? (MODE & 1) != 0 : (p.sAk == 1);
-    const bool b_kc = MODE >= 0 ? (MODE & 2) != 0 : (p.sBk == 1);
+    constexpr bool a_kc = AM != 0, b_kc = BMD != 0;
 
     // staging assignment: each thread moves NA (NB) groups of 4 consecutive k of one row
     int a_row[NA], a_kq[NA], b_row[NB], b_kq[NB];
@@ -140,55 +149,134 @@ __global__ __launch_bounds__(WGM* WGN * 64, (BM == 128 && BN == 128) ? 4 : 1) vo
 
     float rowsum = 0.f;
     float4 ra[NA], rb[NB];
-    // fast path: per-thread base pointers (row clamped into range), advanced by BK*s_k per k-tile
+    // per-thread base pointers (row clamped into range), advanced by BK*s_k per k-tile
     const float* pa[NA];
     const float* pb[NB];
-    if (MODE >= 0) {
+    // loader 2: element (e, u) of a thread is (row = tid/BK + (4e+u)*RSTEP, k = tid%BK); bit 4e+u of the mask = in range
+    const int k2 = tid % BK, r2 = tid / BK;
+    unsigned a_ok = 0, b_ok = 0;
+    const long a_ustep = (long)RSTEP * p.sAi, b_ustep = (long)RSTEP * p.sBj;
+    if (AM == 2) {
+#pragma unroll
+        for (int e = 0; e < NA; ++e) {
+            pa[e] = A + (long)min(row0 + r2 + 4 * e * RSTEP, p.M - 1) * p.sAi + (kbeg + k2);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = r2 + (4 * e + u) * RSTEP;
+                if (row < BM && row0 + row < p.M) a_ok |= 1u << (4 * e + u);
+            }
+        }
+    } else {
 #pragma unroll
         for (int e = 0; e < NA; ++e)
             pa[e] = A + (long)min(row0 + a_row[e], p.M - 1) * p.sAi + (long)(kbeg + a_kq[e] * 4) * p.sAk;
+    }
+    if (BMD == 2) {
+#pragma unroll
+        for (int e = 0; e < NB; ++e) {
+            pb[e] = B + (long)min(col0 + r2 + 4 * e * RSTEP, p.N - 1) * p.sBj + (kbeg + k2);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int col = r2 + (4 * e + u) * RSTEP;
+                if (col < BN && col0 + col < p.N) b_ok |= 1u << (4 * e + u);
+            }
+        }
+    } else {
 #pragma unroll
         for (int e = 0; e < NB; ++e)
             pb[e] = B + (long)min(col0 + b_row[e], p.N - 1) * p.sBj + (long)(kbeg + b_kq[e] * 4) * p.sBk;
     }
+    // loader 2: out-of-range elements read the operand's first element (always valid) and are zeroed
+    auto ld_sel = [&](const float* q, const float* safe, bool ok) -> float {
+        const float v = *(ok ? q : safe);
+        return ok ? v : 0.f;
+    };
     auto fetch = [&](int k0) {
-        if (MODE >= 0 && k0 + BK <= kend) {   // whole k-tile: branch-free loaders; a K tail falls through to the generic ones
+        const bool whole = k0 + BK <= kend;
+        if (AM == 2) {
+            const bool kin = k0 + k2 < kend;
+#pragma unroll
+            for (int e = 0; e < NA; ++e) {
+                ra[e].x = ld_sel(pa[e], A, kin && (a_ok >> (4 * e) & 1));
+                ra[e].y = ld_sel(pa[e] + a_ustep, A, kin && (a_ok >> (4 * e + 1) & 1));
+                ra[e].z = ld_sel(pa[e] + 2 * a_ustep, A, kin && (a_ok >> (4 * e + 2) & 1));
+                ra[e].w = ld_sel(pa[e] + 3 * a_ustep, A, kin && (a_ok >> (4 * e + 3) & 1));
+                pa[e] += BK;
+            }
+        } else if (whole) {
 #pragma unroll
             for (int e = 0; e < NA; ++e)
                 if (BM * KQ % NT == 0 || tid + e * NT < BM * KQ) {
-                    ra[e] = ld4_fast<(MODE & 1) != 0>(pa[e], p.sAk);
+                    ra[e] = ld4_fast<AM == 1>(pa[e], p.sAk);
                     pa[e] += (long)BK * p.sAk;
                 }
+        } else {
+#pragma unroll
+            for (int e = 0; e < NA; ++e) {
+                const int row = row0 + a_row[e];
+                const bool ok = (tid + e * NT < BM * KQ) && row < p.M;
+                ra[e] = ld4(A, (long)row * p.sAi, k0 + a_kq[e] * 4, p.sAk, ok, kend, p.vecA);
+            }
+        }
+        if (BMD == 2) {
+            const bool kin = k0 + k2 < kend;
+#pragma unroll
+            for (int e = 0; e < NB; ++e) {
+                rb[e].x = ld_sel(pb[e], B, kin && (b_ok >> (4 * e) & 1));
+                rb[e].y = ld_sel(pb[e] + b_ustep, B, kin && (b_ok >> (4 * e + 1) & 1));
+                rb[e].z = ld_sel(pb[e] + 2 * b_ustep, B, kin && (b_ok >> (4 * e + 2) & 1));
+                rb[e].w = ld_sel(pb[e] + 3 * b_ustep, B, kin && (b_ok >> (4 * e + 3) & 1));
+                pb[e] += BK;
+            }
+        } else if (whole) {
 #pragma unroll
             for (int e = 0; e < NB; ++e)
                 if (BN * KQ % NT == 0 || tid + e * NT < BN * KQ) {
-                    rb[e] = ld4_fast<(MODE & 2) != 0>(pb[e], p.sBk);
+                    rb[e] = ld4_fast<BMD == 1>(pb[e], p.sBk);
                     pb[e] += (long)BK * p.sBk;
                 }
-            return;
-        }
+        } else {
 #pragma unroll
-        for (int e = 0; e < NA; ++e) {
-            const int row = row0 + a_row[e];
-            const bool ok = (tid + e * NT < BM * KQ) && row < p.M;
-            ra[e] = ld4(A, (long)row * p.sAi, k0 + a_kq[e] * 4, p.sAk, ok, kend, p.vecA);
-        }
-#pragma unroll
-        for (int e = 0; e < NB; ++e) {
-            const int col = col0 + b_row[e];
-            const bool ok = (tid + e * NT < BN * KQ) && col < p.N;
-            rb[e] = ld4(B, (long)col * p.sBj, k0 + b_kq[e] * 4, p.sBk, ok, kend, p.vecB);
+            for (int e = 0; e < NB; ++e) {
+                const int col = col0 + b_row[e];
+                const bool ok = (tid + e * NT < BN * KQ) && col < p.N;
+                rb[e] = ld4(B, (long)col * p.sBj, k0 + b_kq[e] * 4, p.sBk, ok, kend, p.vecB);
+            }
         }
     };
 
     if (kbeg < kend) fetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        if (AM == 2) {
 #pragma unroll
-        for (int e = 0; e < NA; ++e)
-            if (BM * KQ % NT == 0 || tid + e * NT < BM * KQ) *reinterpret_cast<float4*>(&As[a_row[e] * LDK + a_kq[e] * 4]) = ra[e];
+            for (int e = 0; e < NA; ++e) {
+                const int row = r2 + 4 * e * RSTEP;
+                if (row < BM) As[row * LDK + k2] = ra[e].x;
+                if (row + RSTEP < BM) As[(row + RSTEP) * LDK + k2] = ra[e].y;
+                if (row + 2 * RSTEP < BM) As[(row + 2 * RSTEP) * LDK + k2] = ra[e].z;
+                if (row + 3 * RSTEP < BM) As[(row + 3 * RSTEP) * LDK + k2] = ra[e].w;
+            }
+        } else {
 #pragma unroll
-        for (int e = 0; e < NB; ++e)
-            if (BN * KQ % NT == 0 || tid + e * NT < BN * KQ) *reinterpret_cast<float4*>(&Bs[b_row[e] * LDK + b_kq[e] * 4]) = rb[e];
+            for (int e = 0; e < NA; ++e)
+                if (BM * KQ % NT == 0 || tid + e * NT < BM * KQ)
+                    *reinterpret_cast<float4*>(&As[a_row[e] * LDK + a_kq[e] * 4]) = ra[e];
+        }
+        if (BMD == 2) {
+#pragma unroll
+            for (int e = 0; e < NB; ++e) {
+                const int col = r2 + 4 * e * RSTEP;
+                if (col < BN) Bs[col * LDK + k2] = rb[e].x;
+                if (col + RSTEP < BN) Bs[(col + RSTEP) * LDK + k2] = rb[e].y;
+                if (col + 2 * RSTEP < BN) Bs[(col + 2 * RSTEP) * LDK + k2] = rb[e].z;
+                if (col + 3 * RSTEP < BN) Bs[(col + 3 * RSTEP) * LDK + k2] = rb[e].w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < NB; ++e)
+                if (BN * KQ % NT == 0 || tid + e * NT < BN * KQ)
+                    *reinterpret_cast<float4*>(&Bs[b_row[e] * LDK + b_kq[e] * 4]) = rb[e];
+        }
         __syncthreads();
         if (k0 + BK < kend) fetch(k0 + BK);  // next tile's global loads fly under this tile's MFMAs
         if ((p.flags & HP_GEMM_ROWSUM) && tile_n == 0 && tid < BM) {   // bias gradient: row sums of the staged A tile
@@ -414,14 +502,19 @@ int launch_cfg(KParams& p, int batch, hipStream_t stream) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     dim3 grid(p.tiles_m * p.tiles_n, batch * p.ksplit), block(WGM * WGN * 64);
-    // MODE bit = "K-contiguous AND 16-byte loadable"; a K-contiguous operand that is not (e.g. the per-cloud weight
-    // slices of theta, row stride 19011) takes the strided-scalar loader with s_k = 1.  Whole k-tiles use the
-    // branch-free loaders, a K tail (or K < BK) the predicated ones inside the same kernel.
-    const bool a_vk = p.sAk == 1 && p.vecA, b_vk = p.sBk == 1 && p.vecB;
-    if (a_vk && b_vk) hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, 3>), grid, block, 0, stream, p);
-    else if (a_vk) hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, 1>), grid, block, 0, stream, p);
-    else if (b_vk) hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, 2>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, 0>), grid, block, 0, stream, p);
+    // loader per operand (see gemm_kernel): 1 = K-contiguous and 16-byte loadable, 2 = K-contiguous otherwise,
+    // 0 = i/j-contiguous.  The pairs the step produces are instantiated; any other falls back to loader 0, which is
+    // correct for every layout.
+    const int am = p.sAk == 1 ? (p.vecA ? 1 : 2) : 0, bm = p.sBk == 1 ? (p.vecB ? 1 : 2) : 0;
+#define HP_GEMM_LAUNCH(MODE_) hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, MODE_>), grid, block, 0, stream, p)
+    if (am == 1 && bm == 1) HP_GEMM_LAUNCH(4);
+    else if (am == 1 && bm == 2) HP_GEMM_LAUNCH(7);
+    else if (am == 2 && bm == 0) HP_GEMM_LAUNCH(2);
+    else if (am == 2 && bm == 2) HP_GEMM_LAUNCH(8);
+    else if (am == 1) HP_GEMM_LAUNCH(1);
+    else if (bm == 1) HP_GEMM_LAUNCH(3);
+    else HP_GEMM_LAUNCH(0);
+#undef HP_GEMM_LAUNCH
     return (int)hipGetLastError();
 }
 

@@ -91,6 +91,7 @@ def test_two_rank_engine_matches_single_process_global_batch():
         ex, mi, gt, pts, eps = (t.cuda() for t in _data())
         for _ in range(2):
             eng.step(ex, mi, gt, 7, points=pts, eps_noise=eps)
+        eng.finish_pending()
         for k, p in model.named_parameters():
             a, b = got[k].double(), p.detach().cpu().double()
             # Adam's update is ~lr*sign(g): tiny-gradient elements may flip under a different summation order

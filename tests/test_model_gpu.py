@@ -63,7 +63,7 @@ def grad_close(got, want, tol=2e-4):
 
 # ----------------------------------------------------------------------------- GEMM family
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (64, 19, 3), (100, 130, 70), (256, 512, 512), (64, 2112, 2048), (2048, 3, 64),
-                                   (777, 65, 33), (128, 128, 16), (4096, 64, 3)])
+                                   (777, 65, 33), (128, 128, 16), (4096, 64, 3), (64, 200, 1901), (300, 130, 37)])
 @pytest.mark.parametrize("trans_a,trans_b", [(False, True), (False, False), (True, False), (True, True)])
 def test_gemm_layouts(M, N, K, trans_a, trans_b):
     from hyperpocket_amd.ops import gemm
@@ -408,6 +408,7 @@ def test_train_engine_vs_reference_golden():
             assert abs(out["loss_all"].item() - float(g[f"loss_all{s}"])) <= tol * abs(float(g[f"loss_all{s}"])), s
             assert abs(out["loss_kld"].item() - float(g[f"loss_kld{s}"])) <= tol * abs(float(g[f"loss_kld{s}"])), s
             assert ex.shape == (2, 64, 3)      # the engine shields its caller's tensors from forward()'s in-place transpose
+            eng.finish_pending()               # the heads' Adam pass runs on the update stream: order it before the reads
             for k, p in model.named_parameters():
                 want = g[f"psum{s}__" + k.replace(".", "__")]
                 assert abs(p.double().norm().item() - want[1]) <= ptol * want[1] + 1e-9, (s, k)
@@ -457,6 +458,7 @@ def test_train_engine_chamfer_plus_emd_step_vs_oracle(ref):
         assert abs(out["loss_r"].item() - loss_r.item()) <= 1e-5 * abs(loss_r.item())
         want_emd = loss_all.item() - loss_r.item() - kld.item()
         assert abs(out["loss_emd"].item() - want_emd) <= 1e-3 * abs(want_emd) + 1e-2   # difference of large numbers on the oracle side
+        eng.finish_pending()
         for k, p in model.named_parameters():
             a, b = p.detach().cpu().double().norm().item(), P[k].double().norm().item()
             assert abs(a - b) <= 1e-5 * b + 1e-9, k
@@ -483,6 +485,7 @@ def test_baseline_config4_hyperrec_full_size_step(ref):
         loss_all, loss_r, kld, rec, _ = ref.train_step(P, ref.Adam(P), partial, None, gt, pts, None)
         assert kld is None and "loss_kld" not in out
         assert abs(out["loss_all"].item() - loss_all.item()) <= 1e-5 * abs(loss_all.item())
+        eng.finish_pending()
         for k, p in model.named_parameters():
             a, b = p.detach().cpu().double().norm().item(), P[k].double().norm().item()
             assert abs(a - b) <= 1e-5 * b + 1e-9, k
