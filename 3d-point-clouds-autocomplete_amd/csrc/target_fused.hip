@@ -1,0 +1,415 @@
+// Fused per-cloud target network for gfx950 — the published HyperPocket decoder 3 -> 32 -> 64 -> 128 -> 64 -> 3
+// (/root/reference/model/target_network.py:6-45 with settings/hyperparams.json "target_network").
+//
+// The reference builds one TargetNetwork object per cloud and runs 5 torch.mm + 4 ReLU launches on (2048, C)
+// tensors (model/full_model.py:70-74).  The layered path in model.hip batches those into one GEMM per layer, but
+// every layer still round-trips its (B*N, C) activations through HBM — 290 MB forward, ~750 MB backward at B=64 —
+// and K <= 128 leaves each GEMM workgroup three k-tiles of work between a cold prologue and a 64 KB epilogue.
+//
+// Here a cloud's whole weight vector (19 011 floats, 77 KB) is parked in LDS and the activations of 32 points
+// never leave a wave's registers:
+//   * "points as columns": a layer is Z (Cout x 32 pts) = W (Cout x Cin) . H (Cin x 32 pts) on
+//     v_mfma_f32_32x32x2_f32.  A = W rows from LDS (odd leading dimension: conflict-free), B = the previous
+//     layer's accumulator registers USED AS THEY ARE: the C/D layout of a 32x32 tile puts row
+//     kmap(e,h) = (e&3) + 8(e>>2) + 4h in register e of lane half h, and a contraction may visit k in any
+//     order, so MFMA step s simply takes k = kmap(s,h): no shuffles, no LDS between layers.
+//   * backward recomputes the forward from (points, theta) — nothing is saved by the forward at all — then runs
+//     dX the same way (A = W^T read from the same LDS image) and the ReLU mask from the live registers.
+//   * dW = Delta . H^T contracts over points, which live in lanes: the Delta/H tiles of 64 points are
+//     transposed through a 70 KB LDS stage ([channel][point], 68-float rows: conflict-free ds_read_b128) and the
+//     dW tiles are partitioned over the 4 waves, which keep them in accumulators across the workgroup's whole
+//     point range.  Bias gradients ride on the A fragments (row sums); dW1/db1 come from one padded tile
+//     ([x y z 1] as the B operand).
+//   * each workgroup writes its partial d theta; a small kernel adds the partials of a cloud in workgroup order
+//     (ordered, atomic-free).
+// HBM traffic: points + theta + y forward; points + theta + grad_y + S partial d theta backward.
+#include "hp_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int C1 = 32, C2 = 64, C3 = 128, C4 = 64;
+// theta layout [W1 b1 | W2 b2 | W3 b3 | W4 b4 | W5 b5], W row-major (out, in)   (model/target_network.py:18-29)
+constexpr int OW1 = 0, OB1 = OW1 + C1 * 3, OW2 = OB1 + C1, OB2 = OW2 + C2 * C1, OW3 = OB2 + C2, OB3 = OW3 + C3 * C2,
+              OW4 = OB3 + C3, OB4 = OW4 + C4 * C3, OW5 = OB4 + C4, OB5 = OW5 + 3 * C4, kTheta = OB5 + 3;
+static_assert(kTheta == 19011, "theta size of the published target network");
+// LDS image of theta: the three MFMA weight matrices get odd leading dimensions
+constexpr int LD2 = C1 + 1, LD3 = C2 + 1, LD4 = C3 + 1;
+constexpr int SW1 = 0, SB1 = SW1 + C1 * 3, SW5 = SB1 + C1, SB5 = SW5 + 3 * C4, SB2 = SB5 + 4, SB3 = SB2 + C2, SB4 = SB3 + C3,
+              SW2 = SB4 + C4, SW3 = SW2 + C2 * LD2, SW4 = SW3 + C3 * LD3, kWFloats = SW4 + C4 * LD4;
+static_assert(kWFloats % 4 == 0, "the stage behind the weights must stay 16-byte aligned");
+// transposed stage: [channel row][64 points], 68-float rows
+constexpr int kStagePts = 64, LDS_ST = kStagePts + 4;
+constexpr int kStageRows = 4 + C4 + C4 + C3;   // largest group: grad_y (3 -> 4), H4, Delta4, H3
+constexpr int kStageFloats = kStageRows * LDS_ST;
+constexpr int kBwdLds = kWFloats + kStageFloats;
+static_assert(kBwdLds * 4 <= 160 * 1024, "LDS budget of a CU");
+
+__device__ __forceinline__ int kmap(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// theta of one cloud -> LDS image (all threads of the workgroup)
+__device__ __forceinline__ void load_theta(const float* __restrict__ th, float* __restrict__ lds, int tid, int nthreads) {
+    for (int i = tid; i < C1 * 3 + C1; i += nthreads) lds[SW1 + i] = th[OW1 + i];           // W1, b1 (contiguous in both)
+    for (int i = tid; i < 3 * C4 + 3; i += nthreads) lds[SW5 + i] = th[OW5 + i];            // W5, b5
+    for (int i = tid; i < C2; i += nthreads) lds[SB2 + i] = th[OB2 + i];
+    for (int i = tid; i < C3; i += nthreads) lds[SB3 + i] = th[OB3 + i];
+    for (int i = tid; i < C4; i += nthreads) lds[SB4 + i] = th[OB4 + i];
+    for (int i = tid; i < C2 * C1; i += nthreads) lds[SW2 + (i / C1) * LD2 + (i % C1)] = th[OW2 + i];
+    for (int i = tid; i < C3 * C2; i += nthreads) lds[SW3 + (i / C2) * LD3 + (i % C2)] = th[OW3 + i];
+    for (int i = tid; i < C4 * C3; i += nthreads) lds[SW4 + (i / C3) * LD4 + (i % C3)] = th[OW4 + i];
+}
+
+// layer 1 (3 -> 32) on the VALU: h1[e] = relu(W1[c] . p + b1[c]),  c = kmap(e,h)      (model/target_network.py:33-36)
+__device__ __forceinline__ void layer1(const float* __restrict__ lds, float x, float y, float z, int h, f32x16& h1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int c = kmap(e, h);
+        float t = x * lds[SW1 + c * 3];
+        t = __builtin_fmaf(y, lds[SW1 + c * 3 + 1], t);
+        t = __builtin_fmaf(z, lds[SW1 + c * 3 + 2], t);
+        h1[e] = fmaxf(t + lds[SB1 + c], 0.f);
+    }
+}
+
+// hidden layer: out (TO tiles) = relu(W (32*TO x 32*TI, lds, leading dim LD) . in (TI tiles) + b)
+template <int TI, int TO, int LD>
+__device__ __forceinline__ void layer_fwd(const float* __restrict__ W, const float* __restrict__ b, const f32x16 (&in)[TI],
+                                          f32x16 (&out)[TO], int r, int h) {
+#pragma unroll
+    for (int to = 0; to < TO; ++to) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc = mfma(W[(to * 32 + r) * LD + ti * 32 + kmap(s, h)], in[ti][s], acc);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) out[to][e] = fmaxf(acc[e] + b[to * 32 + kmap(e, h)], 0.f);
+    }
+}
+
+// output layer (64 -> 3) on the VALU: each lane half holds half of the channels of its point
+__device__ __forceinline__ void layer_out(const float* __restrict__ lds, const f32x16 (&h4)[2], int h, float (&y)[3]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float t = 0.f;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) t = __builtin_fmaf(lds[SW5 + c * C4 + ti * 32 + kmap(e, h)], h4[ti][e], t);
+        t += __shfl_xor(t, 32, 64);
+        y[c] = t + lds[SB5 + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward: 8 waves per workgroup, 32 points per wave per iteration; 2 workgroups per CU (77 KB LDS each)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void target_fwd_kernel(int N, int iters, const float* __restrict__ theta, int theta_ld,
+                                                         const float* __restrict__ pts, float* __restrict__ yout) {
+    __shared__ __attribute__((aligned(16))) float lds[kWFloats];
+    const int cloud = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    load_theta(theta + (long)cloud * theta_ld, lds, tid, 512);
+    __syncthreads();
+    const float* P = pts + (long)cloud * N * 3;
+    float* Y = yout + (long)cloud * N * 3;
+    for (int it = 0; it < iters; ++it) {
+        const int p0 = (blockIdx.x * iters + it) * 256 + wave * 32;
+        if (p0 >= N) break;
+        const int pt = p0 + r, pc = min(pt, N - 1);
+        const float x = P[pc * 3], y = P[pc * 3 + 1], z = P[pc * 3 + 2];
+        f32x16 h1[1], h2[2], h3[4], h4[2];
+        layer1(lds, x, y, z, h, h1[0]);
+        layer_fwd<1, 2, LD2>(lds + SW2, lds + SB2, h1, h2, r, h);
+        layer_fwd<2, 4, LD3>(lds + SW3, lds + SB3, h2, h3, r, h);
+        layer_fwd<4, 2, LD4>(lds + SW4, lds + SB4, h3, h4, r, h);
+        float o[3];
+        layer_out(lds, h4, h, o);
+        if (h == 0 && pt < N) {
+            Y[pt * 3] = o[0];
+            Y[pt * 3 + 1] = o[1];
+            Y[pt * 3 + 2] = o[2];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+// dX: out (TI tiles, Cin) = (W^T . delta (TO tiles, Cout)) * (hprev > 0);  W (32*TO x 32*TI) in lds
+template <int TO, int TI, int LD>
+__device__ __forceinline__ void layer_dx(const float* __restrict__ W, const f32x16 (&delta)[TO], const f32x16 (&hprev)[TI],
+                                         f32x16 (&out)[TI], int r, int h) {
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int to = 0; to < TO; ++to)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc = mfma(W[(to * 32 + kmap(s, h)) * LD + ti * 32 + r], delta[to][s], acc);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) out[ti][e] = hprev[ti][e] > 0.f ? acc[e] : 0.f;
+    }
+}
+
+// registers (channels x this wave's 32 points) -> stage rows [row0 + channel][pl + point]
+template <int T>
+__device__ __forceinline__ void stage_put(float* __restrict__ st, int row0, const f32x16 (&v)[T], int pl, int h) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) st[(row0 + t * 32 + kmap(e, h)) * LDS_ST + pl] = v[t][e];
+}
+
+// acc (32 x 32) += A(rows arow..+31 of the stage) . B(rows brow..+31)^T over the 64 staged points; returns the sum of
+// this lane's A fragments (its row's partial bias gradient).  a_rows / b_rows: rows >= that count read as 0, and
+// B row == b_rows reads as 1 when `b_one` (the [x y z 1] operand of layer 1).
+template <bool A_PAD, bool B_PAD>
+__device__ __forceinline__ float dw_tile(const float* __restrict__ st, int arow, int brow, int r, int h, f32x16& acc,
+                                         int a_rows = 32, int b_rows = 32, bool b_one = false) {
+    float asum = 0.f;
+    const bool a_zero = A_PAD && r >= a_rows;
+    const bool b_zero = B_PAD && r >= b_rows, b_is_one = B_PAD && b_one && r == b_rows;
+    const float* ap = st + (arow + (a_zero ? 0 : r)) * LDS_ST + 4 * h;
+    const float* bp = st + (brow + ((b_zero) ? 0 : r)) * LDS_ST + 4 * h;
+#pragma unroll
+    for (int q = 0; q < kStagePts / 8; ++q) {
+        float4 a = *reinterpret_cast<const float4*>(ap + 8 * q);
+        float4 b = *reinterpret_cast<const float4*>(bp + 8 * q);
+        if (A_PAD && a_zero) a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (B_PAD && b_zero) b = b_is_one ? make_float4(1.f, 1.f, 1.f, 1.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+        asum += (a.x + a.y) + (a.z + a.w);
+        acc = mfma(a.x, b.x, acc);
+        acc = mfma(a.y, b.y, acc);
+        acc = mfma(a.z, b.z, acc);
+        acc = mfma(a.w, b.w, acc);
+    }
+    return asum;
+}
+
+// stage row groups
+constexpr int RA_GY = 0, RA_H4 = 4, RA_D4 = RA_H4 + C4, RA_H3 = RA_D4 + C4;   // group A: 260 rows
+constexpr int RB_D3 = 0, RB_H2 = C3;                                          // group B: 192 rows
+constexpr int RC_D2 = 0, RC_H1 = C2, RC_D1 = RC_H1 + C1, RC_H0 = RC_D1 + C1;   // group C: 131 rows
+
+// One workgroup = 4 waves = 128 points per iteration, `iters` iterations; grid (S, B).  partial: (B, S, kTheta).
+__global__ __launch_bounds__(256, 1) void target_bwd_kernel(int N, int iters, const float* __restrict__ theta, int theta_ld,
+                                                            const float* __restrict__ pts, const float* __restrict__ gy,
+                                                            float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float lds[kBwdLds];
+    float* st = lds + kWFloats;
+    const int cloud = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    load_theta(theta + (long)cloud * theta_ld, lds, tid, 256);
+    const float* P = pts + (long)cloud * N * 3;
+    const float* G = gy + (long)cloud * N * 3;
+
+    // this wave's share of d theta (see the table in the file header)
+    f32x16 acc4[2], acc3[2], accs, acc1;   // dW4[:, wave-th cin tile], dW3[wave-th cout tile, :], small tile, dW1|db1
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        acc4[0][e] = acc4[1][e] = acc3[0][e] = acc3[1][e] = accs[e] = acc1[e] = 0.f;
+    }
+    float db4[2] = {0.f, 0.f}, db3 = 0.f, dbs = 0.f;   // row sums of this lane's A fragments
+    const int pl = (wave & 1) * 32 + r;                // this lane's point inside a 64-point stage half
+
+    for (int it = 0; it < iters; ++it) {
+        const int p0 = (blockIdx.x * iters + it) * 128;
+        if (p0 >= N) break;                            // uniform over the workgroup
+        const int pt = p0 + wave * 32 + r, pc = min(pt, N - 1);
+        const bool live = pt < N;
+        const float x = P[pc * 3], y = P[pc * 3 + 1], z = P[pc * 3 + 2];
+        float g[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g[c] = live ? G[pc * 3 + c] : 0.f;
+        if (it == 0) __syncthreads();                  // theta image complete
+
+        // ---- recompute the forward
+        f32x16 h1[1], h2[2], h3[4], h4[2];
+        layer1(lds, x, y, z, h, h1[0]);
+        layer_fwd<1, 2, LD2>(lds + SW2, lds + SB2, h1, h2, r, h);
+        layer_fwd<2, 4, LD3>(lds + SW3, lds + SB3, h2, h3, r, h);
+        layer_fwd<4, 2, LD4>(lds + SW4, lds + SB4, h3, h4, r, h);
+
+        // ---- delta4 = (W5^T grad_y) * (h4 > 0)
+        f32x16 d4[2];
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = ti * 32 + kmap(e, h);
+                float t = g[0] * lds[SW5 + k];
+                t = __builtin_fmaf(g[1], lds[SW5 + C4 + k], t);
+                t = __builtin_fmaf(g[2], lds[SW5 + 2 * C4 + k], t);
+                d4[ti][e] = h4[ti][e] > 0.f ? t : 0.f;
+            }
+
+        // ---- group A: dW5 (+db5), dW4 (+db4)
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();
+            if ((wave >> 1) == half) {
+                if (h == 0) {
+                    st[(RA_GY + 0) * LDS_ST + pl] = g[0];
+                    st[(RA_GY + 1) * LDS_ST + pl] = g[1];
+                    st[(RA_GY + 2) * LDS_ST + pl] = g[2];
+                }
+                stage_put<2>(st, RA_H4, h4, pl, h);
+                stage_put<2>(st, RA_D4, d4, pl, h);
+                stage_put<4>(st, RA_H3, h3, pl, h);
+            }
+            __syncthreads();
+            const float s0 = dw_tile<false, false>(st, RA_D4, RA_H3 + wave * 32, r, h, acc4[0]);
+            const float s1 = dw_tile<false, false>(st, RA_D4 + 32, RA_H3 + wave * 32, r, h, acc4[1]);
+            if (wave == 0) {
+                db4[0] += s0;
+                db4[1] += s1;
+            }
+            if (wave >= 2) {
+                const float s5 = dw_tile<true, false>(st, RA_GY, RA_H4 + (wave - 2) * 32, r, h, accs, 3);
+                if (wave == 2) dbs += s5;
+            }
+        }
+
+        // ---- delta3, group B: dW3 (+db3)
+        f32x16 d3[4];
+        layer_dx<2, 4, LD4>(lds + SW4, d4, h3, d3, r, h);
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();
+            if ((wave >> 1) == half) {
+                stage_put<4>(st, RB_D3, d3, pl, h);
+                stage_put<2>(st, RB_H2, h2, pl, h);
+            }
+            __syncthreads();
+            db3 += dw_tile<false, false>(st, RB_D3 + wave * 32, RB_H2, r, h, acc3[0]);
+            (void)dw_tile<false, false>(st, RB_D3 + wave * 32, RB_H2 + 32, r, h, acc3[1]);
+        }
+
+        // ---- delta2, delta1, group C: dW2 (+db2), dW1|db1
+        f32x16 d2[2], d1[1];
+        layer_dx<4, 2, LD3>(lds + SW3, d3, h2, d2, r, h);
+        layer_dx<2, 1, LD2>(lds + SW2, d2, h1, d1, r, h);
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();
+            if ((wave >> 1) == half) {
+                stage_put<2>(st, RC_D2, d2, pl, h);
+                stage_put<1>(st, RC_H1, h1, pl, h);
+                stage_put<1>(st, RC_D1, d1, pl, h);
+                if (h == 0) {
+                    st[(RC_H0 + 0) * LDS_ST + pl] = x;
+                    st[(RC_H0 + 1) * LDS_ST + pl] = y;
+                    st[(RC_H0 + 2) * LDS_ST + pl] = z;
+                }
+            }
+            __syncthreads();
+            if (wave < 2) dbs += dw_tile<false, false>(st, RC_D2 + wave * 32, RC_H1, r, h, accs);
+            if (wave == 3) (void)dw_tile<false, true>(st, RC_D1, RC_H0, r, h, acc1, 32, 3, true);
+        }
+    }
+
+    // ---- this workgroup's partial d theta, theta layout.  D tile: row = kmap(e,h), col = r.
+    float* out = partial + ((long)cloud * gridDim.x + blockIdx.x) * kTheta;
+#pragma unroll
+    for (int to = 0; to < 2; ++to)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) out[OW4 + (to * 32 + kmap(e, h)) * C3 + wave * 32 + r] = acc4[to][e];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) out[OW3 + (wave * 32 + kmap(e, h)) * C2 + ti * 32 + r] = acc3[ti][e];
+    {
+        const float t = db3 + __shfl_xor(db3, 32, 64);
+        if (h == 0) out[OB3 + wave * 32 + r] = t;
+    }
+    if (wave < 2) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) out[OW2 + (wave * 32 + kmap(e, h)) * C1 + r] = accs[e];
+        const float t = dbs + __shfl_xor(dbs, 32, 64);
+        if (h == 0) out[OB2 + wave * 32 + r] = t;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int c = kmap(e, h);
+            if (c < 3) out[OW5 + c * C4 + (wave - 2) * 32 + r] = accs[e];
+        }
+        if (wave == 2) {
+            const float t = dbs + __shfl_xor(dbs, 32, 64);
+            if (h == 0 && r < 3) out[OB5 + r] = t;
+        }
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int to = 0; to < 2; ++to) {
+            const float t = db4[to] + __shfl_xor(db4[to], 32, 64);
+            if (h == 0) out[OB4 + to * 32 + r] = t;
+        }
+    }
+    if (wave == 3) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int c = kmap(e, h);
+            if (r < 3) out[OW1 + c * 3 + r] = acc1[e];
+            else if (r == 3) out[OB1 + c] = acc1[e];
+        }
+    }
+}
+
+// grad_theta[b][i] = sum_s partial[b][s][i], s ascending
+__global__ __launch_bounds__(256) void target_reduce_kernel(int S, const float* __restrict__ partial, float* __restrict__ gth,
+                                                            int theta_ld) {
+    const int cloud = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kTheta) return;
+    const float* p = partial + (long)cloud * S * kTheta + i;
+    float v = 0.f;
+#pragma unroll 4
+    for (int s = 0; s < S; ++s) v += p[(long)s * kTheta];
+    gth[(long)cloud * theta_ld + i] = v;
+}
+
+// workgroups per cloud for the backward: enough to cover the chip, each at least one 128-point iteration
+int bwd_splits(int B, int N) {
+    const int blocks = (N + 127) / 128;
+    int s = (512 + B - 1) / B;
+    if (s > blocks) s = blocks;
+    if (s > 16) s = 16;
+    return s < 1 ? 1 : s;
+}
+
+}  // namespace
+
+// 1 when (n_hidden, channels) is the architecture these kernels are written for
+HP_API int hp_target_fused_supported(int n_hidden, const int* channels) {
+    return n_hidden == 4 && channels && channels[0] == C1 && channels[1] == C2 && channels[2] == C3 && channels[3] == C4;
+}
+
+HP_API long hp_target_fused_workspace_floats(int B, int N) { return (long)B * bwd_splits(B, N) * kTheta; }
+
+HP_API int hp_target_fused_forward(int B, int N, const float* theta, int theta_ld, const float* pts, float* y, hipStream_t stream) {
+    HP_CHECK_ARG(B > 0 && B <= 65535 && N > 0 && theta && pts && y && theta_ld >= kTheta);
+    const int blocks = (N + 255) / 256;
+    int per = (blocks * B + 1023) / 1024;              // ~2 rounds of 2 workgroups per CU
+    if (per < 1) per = 1;
+    const int gx = (blocks + per - 1) / per;
+    hipLaunchKernelGGL(target_fwd_kernel, dim3(gx, B), dim3(512), 0, stream, N, per, theta, theta_ld, pts, y);
+    HP_RETURN_LAST_ERROR();
+}
+
+HP_API int hp_target_fused_backward(int B, int N, const float* theta, int theta_ld, const float* pts, const float* grad_y,
+                             float* grad_theta, float* ws, hipStream_t stream) {
+    HP_CHECK_ARG(B > 0 && B <= 65535 && N > 0 && theta && pts && grad_y && grad_theta && ws && theta_ld >= kTheta);
+    const int S = bwd_splits(B, N);
+    const int blocks = (N + 127) / 128;
+    const int iters = (blocks + S - 1) / S;
+    hipLaunchKernelGGL(target_bwd_kernel, dim3(S, B), dim3(256), 0, stream, N, iters, theta, theta_ld, pts, grad_y, ws);
+    hipLaunchKernelGGL(target_reduce_kernel, dim3((kTheta + 255) / 256, B), dim3(256), 0, stream, S, ws, grad_theta, theta_ld);
+    HP_RETURN_LAST_ERROR();
+}

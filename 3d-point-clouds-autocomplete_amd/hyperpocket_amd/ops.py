@@ -182,6 +182,12 @@ class HyperNetFunction(Function):
         return (grad_latent, None, *out)
 
 
+# The published decoder (3-32-64-128-64-3) runs as one fused kernel per direction (csrc/target_fused.hip: weights in
+# LDS, activations in registers, nothing saved for the backward).  False: the layered batched-GEMM path, which serves
+# every other architecture anyway.
+FUSED_TARGET_NETWORK = True
+
+
 class TargetNetworkFunction(Function):
     """All B per-cloud target networks at once (model/full_model.py:70-74 + model/target_network.py).
     theta (B, T), points (B, N, 3) -> y (B, N, 3)."""
@@ -199,21 +205,31 @@ class TargetNetworkFunction(Function):
         if need != theta.size(1) or theta.size(0) != B:
             # model/target_network.py:29 `assert split_index == len(weights)`
             raise HipExtensionError(f"target network expects {need} weights per cloud, got {tuple(theta.shape)}")
-        acts = torch.empty((_long_fn("hp_target_saved_floats", B, N, len(channels), ch),), dtype=torch.float32, device=dev)
         y = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
-        call("hp_target_forward", B, N, len(channels), ch, theta, theta.size(1), points, acts, y, current_stream(dev))
         ctx.channels = tuple(channels)
+        ctx.fused = bool(FUSED_TARGET_NETWORK and load_library().hp_target_fused_supported(len(channels), ch))
+        if ctx.fused:
+            call("hp_target_fused_forward", B, N, theta, theta.size(1), points, y, current_stream(dev))
+            ctx.save_for_backward(theta, points)
+            return y
+        acts = torch.empty((_long_fn("hp_target_saved_floats", B, N, len(channels), ch),), dtype=torch.float32, device=dev)
+        call("hp_target_forward", B, N, len(channels), ch, theta, theta.size(1), points, acts, y, current_stream(dev))
         ctx.save_for_backward(theta, points, acts)
         return y
 
     @staticmethod
     def backward(ctx, grad_y):
-        theta, points, acts = ctx.saved_tensors
         grad_y = grad_y.contiguous()
+        theta, points = ctx.saved_tensors[:2]
         B, N = points.size(0), points.size(1)
         dev = theta.device
-        ch = (c_int * len(ctx.channels))(*ctx.channels)
         grad_theta = torch.empty_like(theta)
+        if ctx.fused:
+            ws = torch.empty((_long_fn("hp_target_fused_workspace_floats", B, N),), dtype=torch.float32, device=dev)
+            call("hp_target_fused_backward", B, N, theta, theta.size(1), points, grad_y, grad_theta, ws, current_stream(dev))
+            return grad_theta, None, None
+        acts = ctx.saved_tensors[2]
+        ch = (c_int * len(ctx.channels))(*ctx.channels)
         ws = torch.empty((_long_fn("hp_target_backward_workspace_floats", B, N, len(ctx.channels), ch),), dtype=torch.float32,
                          device=dev)
         call("hp_target_backward", B, N, len(ctx.channels), ch, theta, theta.size(1), points,

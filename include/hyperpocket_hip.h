@@ -206,6 +206,17 @@ long hp_target_backward_workspace_floats(int B, int N, int n_hidden, const int* 
 int hp_target_backward(int B, int N, int n_hidden, const int* channels, const float* theta, int theta_ld, const float* pts,
                        const float* acts, const float* grad_y, float* grad_theta, float* ws, hpStream_t stream);
 
+/* The same decoder for the published architecture (n_hidden = 4, channels 32/64/128/64; hp_target_fused_supported
+ * says so) as ONE kernel per direction: the cloud's 19 011 weights sit in LDS, activations stay in registers, the
+ * backward recomputes the forward (nothing is saved) and writes per-workgroup partial d theta into ws
+ * (hp_target_fused_workspace_floats floats), added in order by a second kernel.  Same results as
+ * hp_target_forward / hp_target_backward up to fp32 summation order. */
+int hp_target_fused_supported(int n_hidden, const int* channels);
+long hp_target_fused_workspace_floats(int B, int N);
+int hp_target_fused_forward(int B, int N, const float* theta, int theta_ld, const float* pts, float* y, hpStream_t stream);
+int hp_target_fused_backward(int B, int N, const float* theta, int theta_ld, const float* pts, const float* grad_y,
+                             float* grad_theta, float* ws, hpStream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Auxiliary kernels of the step
  * ------------------------------------------------------------------------------------------ */

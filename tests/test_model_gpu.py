@@ -197,26 +197,68 @@ def test_hypernet_forward_backward_vs_oracle(ref):
         grad_close(p.grad, P["hyper_network." + k].grad)
 
 
-def test_target_network_forward_backward_vs_oracle(ref):
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("B,N", [(3, 333), (2, 2048), (5, 64), (1, 1), (2, 1300)])
+def test_target_network_forward_backward_vs_oracle(ref, fused, B, N):
+    """Both decoder paths (fused kernels: csrc/target_fused.hip; layered batched GEMMs: csrc/model.hip) against the
+    oracle's per-cloud torch.mm chain, at sizes with ragged tails in every tiling (32/64/128/256 points)."""
+    from hyperpocket_amd import ops
     from hyperpocket_amd.model.target_network import TargetNetwork, target_network_batched
     cfg = {"use_bias": True, "layer_out_channels": [32, 64, 128, 64]}
-    g = torch.Generator().manual_seed(8)
-    B, N = 3, 333
+    g = torch.Generator().manual_seed(8 + N)
     theta = torch.randn(B, 19011, generator=g) * 0.2
     pts = torch.rand(B, N, 3, generator=g) * 2 - 1
     th_d, th_r = theta.cuda().requires_grad_(True), theta.clone().requires_grad_(True)
+    ops.FUSED_TARGET_NETWORK = fused
+    try:
+        y = target_network_batched(cfg, th_d, pts.cuda())
+        ry = torch.stack([ref.target_forward(th_r[j], pts[j]) for j in range(B)])
+        close(y, ry, rtol=1e-5, atol=1e-5)
+        w = torch.randn(B, N, 3, generator=g)
+        (y * w.cuda()).sum().backward()
+        (ry * w).sum().backward()
+        grad_close(th_d.grad, th_r.grad, tol=2e-5)
+        # single-cloud module API of the reference (model/target_network.py:6-38)
+        y1 = TargetNetwork(cfg, theta[B - 1].cuda())(pts[B - 1].cuda())
+        close(y1, ry[B - 1], rtol=1e-5, atol=1e-5)
+        with pytest.raises(Exception):
+            TargetNetwork(cfg, theta[0, :-1].cuda())
+    finally:
+        ops.FUSED_TARGET_NETWORK = True
+
+
+def test_target_network_other_architecture_uses_layered_path(ref):
+    """An architecture the fused kernels are not written for goes through the batched GEMMs."""
+    from hyperpocket_amd.model.target_network import target_network_batched
+    from hyperpocket_amd._lib import load_library
+    import ctypes
+    ch = [16, 48, 24]
+    assert load_library().hp_target_fused_supported(3, (ctypes.c_int * 3)(*ch)) == 0
+    assert load_library().hp_target_fused_supported(4, (ctypes.c_int * 4)(32, 64, 128, 64)) == 1
+    cfg = {"use_bias": True, "layer_out_channels": ch}
+    T = 3 * 16 + 16 + 16 * 48 + 48 + 48 * 24 + 24 + 24 * 3 + 3
+    g = torch.Generator().manual_seed(3)
+    theta = torch.randn(2, T, generator=g) * 0.3
+    pts = torch.rand(2, 100, 3, generator=g) * 2 - 1
+    th_d = theta.cuda().requires_grad_(True)
     y = target_network_batched(cfg, th_d, pts.cuda())
-    ry = torch.stack([ref.target_forward(th_r[j], pts[j]) for j in range(B)])
+    th_r = theta.clone().double().requires_grad_(True)
+    outs = []
+    for b in range(2):
+        hcur, off, cin = pts[b].double(), 0, 3
+        for li, cout in enumerate(ch + [3]):
+            W = th_r[b, off:off + cin * cout].view(cout, cin); off += cin * cout
+            bias = th_r[b, off:off + cout]; off += cout
+            hcur = hcur @ W.t() + bias
+            if li < len(ch):
+                hcur = torch.relu(hcur)
+            cin = cout
+        outs.append(hcur)
+    ry = torch.stack(outs)
     close(y, ry, rtol=1e-5, atol=1e-5)
-    w = torch.randn(B, N, 3, generator=g)
-    (y * w.cuda()).sum().backward()
-    (ry * w).sum().backward()
-    grad_close(th_d.grad, th_r.grad)
-    # single-cloud module API of the reference (model/target_network.py:6-38)
-    y1 = TargetNetwork(cfg, theta[1].cuda())(pts[1].cuda())
-    close(y1, ry[1], rtol=1e-5, atol=1e-5)
-    with pytest.raises(Exception):
-        TargetNetwork(cfg, theta[1, :-1].cuda())
+    (y * y).sum().backward()
+    (ry * ry).sum().backward()
+    grad_close(th_d.grad, th_r.grad, tol=2e-5)
 
 
 # ----------------------------------------------------------------------------- FullModel vs the reference fixtures
