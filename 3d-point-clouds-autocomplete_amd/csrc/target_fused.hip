@@ -9,7 +9,7 @@
 // Here a cloud's whole weight vector (19 011 floats, 77 KB) is parked in LDS and the activations of 32 points
 // never leave a wave's registers:
 //   * "points as columns": a layer is Z (Cout x 32 pts) = W (Cout x Cin) . H (Cin x 32 pts) on
-//     v_mfma_f32_32x32x2_f32.  A = W rows from LDS (odd leading dimension: conflict-free), B = the previous
+//     v_mfma_f32_32x32x2_f32.  A = W rows from LDS (padded leading dimension: conflict-free), B = the previous
 //     layer's accumulator registers USED AS THEY ARE: the C/D layout of a 32x32 tile puts row
 //     kmap(e,h) = (e&3) + 8(e>>2) + 4h in register e of lane half h, and a contraction may visit k in any
 //     order, so MFMA step s simply takes k = kmap(s,h): no shuffles, no LDS between layers.
@@ -34,8 +34,9 @@ constexpr int C1 = 32, C2 = 64, C3 = 128, C4 = 64;
 constexpr int OW1 = 0, OB1 = OW1 + C1 * 3, OW2 = OB1 + C1, OB2 = OW2 + C2 * C1, OW3 = OB2 + C2, OB3 = OW3 + C3 * C2,
               OW4 = OB3 + C3, OB4 = OW4 + C4 * C3, OW5 = OB4 + C4, OB5 = OW5 + 3 * C4, kTheta = OB5 + 3;
 static_assert(kTheta == 19011, "theta size of the published target network");
-// LDS image of theta: the three MFMA weight matrices get odd leading dimensions
-constexpr int LD2 = C1 + 1, LD3 = C2 + 1, LD4 = C3 + 1;
+// LDS image of theta: the three MFMA weight matrices get leading dimensions = 4 (mod 32): 16-byte aligned rows,
+// conflict-free for the forward's ds_read_b128 (32 rows x 4 consecutive k) and the backward's ds_read_b32 (32 consecutive i)
+constexpr int LD2 = C1 + 4, LD3 = C2 + 4, LD4 = C3 + 4;
 constexpr int SW1 = 0, SB1 = SW1 + C1 * 3, SW5 = SB1 + C1, SB5 = SW5 + 3 * C4, SB2 = SB5 + 4, SB3 = SB2 + C2, SB4 = SB3 + C3,
               SW2 = SB4 + C4, SW3 = SW2 + C2 * LD2, SW4 = SW3 + C3 * LD3, kWFloats = SW4 + C4 * LD4;
 static_assert(kWFloats % 4 == 0, "the stage behind the weights must stay 16-byte aligned");
@@ -52,16 +53,36 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// n floats of theta -> lds rows of `cin` floats with leading dimension ld; 8 loads are in flight per thread (a
+// load-store loop one element deep would pay the L2 latency 40-80 times over)
+template <int NT>
+__device__ __forceinline__ void copy_rows(const float* __restrict__ src, float* __restrict__ dst, int n, int cin, int ld, int tid) {
+    for (int base = 0; base < n; base += 8 * NT) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * NT + tid;
+            v[u] = i < n ? src[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * NT + tid;
+            if (i < n) dst[(i / cin) * ld + (i % cin)] = v[u];
+        }
+    }
+}
+
 // theta of one cloud -> LDS image (all threads of the workgroup)
-__device__ __forceinline__ void load_theta(const float* __restrict__ th, float* __restrict__ lds, int tid, int nthreads) {
-    for (int i = tid; i < C1 * 3 + C1; i += nthreads) lds[SW1 + i] = th[OW1 + i];           // W1, b1 (contiguous in both)
-    for (int i = tid; i < 3 * C4 + 3; i += nthreads) lds[SW5 + i] = th[OW5 + i];            // W5, b5
-    for (int i = tid; i < C2; i += nthreads) lds[SB2 + i] = th[OB2 + i];
-    for (int i = tid; i < C3; i += nthreads) lds[SB3 + i] = th[OB3 + i];
-    for (int i = tid; i < C4; i += nthreads) lds[SB4 + i] = th[OB4 + i];
-    for (int i = tid; i < C2 * C1; i += nthreads) lds[SW2 + (i / C1) * LD2 + (i % C1)] = th[OW2 + i];
-    for (int i = tid; i < C3 * C2; i += nthreads) lds[SW3 + (i / C2) * LD3 + (i % C2)] = th[OW3 + i];
-    for (int i = tid; i < C4 * C3; i += nthreads) lds[SW4 + (i / C3) * LD4 + (i % C3)] = th[OW4 + i];
+template <int NT>
+__device__ __forceinline__ void load_theta(const float* __restrict__ th, float* __restrict__ lds, int tid) {
+    copy_rows<NT>(th + OW4, lds + SW4, C4 * C3, C3, LD4, tid);
+    copy_rows<NT>(th + OW3, lds + SW3, C3 * C2, C2, LD3, tid);
+    copy_rows<NT>(th + OW2, lds + SW2, C2 * C1, C1, LD2, tid);
+    for (int i = tid; i < C1 * 3 + C1; i += NT) lds[SW1 + i] = th[OW1 + i];           // W1, b1 (contiguous in both)
+    for (int i = tid; i < 3 * C4 + 3; i += NT) lds[SW5 + i] = th[OW5 + i];            // W5, b5
+    for (int i = tid; i < C2; i += NT) lds[SB2 + i] = th[OB2 + i];
+    for (int i = tid; i < C3; i += NT) lds[SB3 + i] = th[OB3 + i];
+    for (int i = tid; i < C4; i += NT) lds[SB4 + i] = th[OB4 + i];
 }
 
 // layer 1 (3 -> 32) on the VALU: h1[e] = relu(W1[c] . p + b1[c]),  c = kmap(e,h)      (model/target_network.py:33-36)
@@ -76,21 +97,50 @@ __device__ __forceinline__ void layer1(const float* __restrict__ lds, float x, f
     }
 }
 
-// hidden layer: out (TO tiles) = relu(W (32*TO x 32*TI, lds, leading dim LD) . in (TI tiles) + b)
+// hidden layer: out (TO tiles) = relu(W (32*TO x 32*TI, lds, leading dim LD) . in (TI tiles) + b).
+// Output tiles are computed two at a time: the two accumulation chains are independent (back-to-back MFMAs on one
+// accumulator wait for each other) and share their B operand.  Four MFMA steps (k = 8j+4h .. +3, contiguous in a
+// W row) take one ds_read_b128 per tile, issued one block ahead of the MFMAs that consume it: with one or two
+// waves per SIMD nothing else hides the LDS latency.
 template <int TI, int TO, int LD>
 __device__ __forceinline__ void layer_fwd(const float* __restrict__ W, const float* __restrict__ b, const f32x16 (&in)[TI],
                                           f32x16 (&out)[TO], int r, int h) {
+    static_assert(TO % 2 == 0, "output tiles come in pairs");
+    constexpr int NB = TI * 4;
 #pragma unroll
-    for (int to = 0; to < TO; ++to) {
-        f32x16 acc;
+    for (int to = 0; to < TO; to += 2) {
+        const float* w0 = W + (to * 32 + r) * LD + 4 * h;
+        const float* w1 = w0 + 32 * LD;
+        f32x16 acc0, acc1;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc0[e] = acc1[e] = 0.f;
+        float4 a0 = *reinterpret_cast<const float4*>(w0), a1 = *reinterpret_cast<const float4*>(w1);
 #pragma unroll
-        for (int ti = 0; ti < TI; ++ti)
+        for (int blk = 0; blk < NB; ++blk) {
+            float4 n0 = a0, n1 = a1;
+            if (blk + 1 < NB) {
+                n0 = *reinterpret_cast<const float4*>(w0 + 8 * (blk + 1));
+                n1 = *reinterpret_cast<const float4*>(w1 + 8 * (blk + 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int ti = blk >> 2, s = (blk & 3) * 4;
+            acc0 = mfma(a0.x, in[ti][s], acc0);
+            acc1 = mfma(a1.x, in[ti][s], acc1);
+            acc0 = mfma(a0.y, in[ti][s + 1], acc0);
+            acc1 = mfma(a1.y, in[ti][s + 1], acc1);
+            acc0 = mfma(a0.z, in[ti][s + 2], acc0);
+            acc1 = mfma(a1.z, in[ti][s + 2], acc1);
+            acc0 = mfma(a0.w, in[ti][s + 3], acc0);
+            acc1 = mfma(a1.w, in[ti][s + 3], acc1);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = n0;
+            a1 = n1;
+        }
 #pragma unroll
-            for (int s = 0; s < 16; ++s) acc = mfma(W[(to * 32 + r) * LD + ti * 32 + kmap(s, h)], in[ti][s], acc);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) out[to][e] = fmaxf(acc[e] + b[to * 32 + kmap(e, h)], 0.f);
+        for (int e = 0; e < 16; ++e) {
+            out[to][e] = fmaxf(acc0[e] + b[to * 32 + kmap(e, h)], 0.f);
+            out[to + 1][e] = fmaxf(acc1[e] + b[to * 32 + 32 + kmap(e, h)], 0.f);
+        }
     }
 }
 
@@ -115,7 +165,7 @@ __global__ __launch_bounds__(512) void target_fwd_kernel(int N, int iters, const
                                                          const float* __restrict__ pts, float* __restrict__ yout) {
     __shared__ __attribute__((aligned(16))) float lds[kWFloats];
     const int cloud = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    load_theta(theta + (long)cloud * theta_ld, lds, tid, 512);
+    load_theta<512>(theta + (long)cloud * theta_ld, lds, tid);
     __syncthreads();
     const float* P = pts + (long)cloud * N * 3;
     float* Y = yout + (long)cloud * N * 3;
@@ -142,21 +192,56 @@ __global__ __launch_bounds__(512) void target_fwd_kernel(int N, int iters, const
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
-// dX: out (TI tiles, Cin) = (W^T . delta (TO tiles, Cout)) * (hprev > 0);  W (32*TO x 32*TI) in lds
+// dX: out (TI tiles, Cin) = (W^T . delta (TO tiles, Cout)) * (hprev > 0);  W (32*TO x 32*TI) in lds.
+// Two output tiles at a time where there are two; A fragments (4 rows of W per block, ds_read_b32 each) are fetched
+// one block ahead like the forward's.
 template <int TO, int TI, int LD>
 __device__ __forceinline__ void layer_dx(const float* __restrict__ W, const f32x16 (&delta)[TO], const f32x16 (&hprev)[TI],
                                          f32x16 (&out)[TI], int r, int h) {
+    constexpr int STEP = TI % 2 == 0 ? 2 : 1;
+    constexpr int NB = TO * 4;
 #pragma unroll
-    for (int ti = 0; ti < TI; ++ti) {
-        f32x16 acc;
+    for (int ti = 0; ti < TI; ti += STEP) {
+        const float* w = W + (4 * h) * LD + ti * 32 + r;     // block blk: rows 8*blk + 4h + u
+        f32x16 acc0, acc1;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc0[e] = acc1[e] = 0.f;
+        float a0[4], a1[4], n0[4], n1[4];
 #pragma unroll
-        for (int to = 0; to < TO; ++to)
+        for (int u = 0; u < 4; ++u) {
+            a0[u] = w[u * LD];
+            a1[u] = STEP == 2 ? w[u * LD + 32] : 0.f;
+        }
 #pragma unroll
-            for (int s = 0; s < 16; ++s) acc = mfma(W[(to * 32 + kmap(s, h)) * LD + ti * 32 + r], delta[to][s], acc);
+        for (int blk = 0; blk < NB; ++blk) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) out[ti][e] = hprev[ti][e] > 0.f ? acc[e] : 0.f;
+            for (int u = 0; u < 4; ++u) {
+                n0[u] = a0[u];
+                n1[u] = a1[u];
+                if (blk + 1 < NB) {
+                    n0[u] = w[(8 * (blk + 1) + u) * LD];
+                    if (STEP == 2) n1[u] = w[(8 * (blk + 1) + u) * LD + 32];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int to = blk >> 2, s = (blk & 3) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc0 = mfma(a0[u], delta[to][s + u], acc0);
+                if (STEP == 2) acc1 = mfma(a1[u], delta[to][s + u], acc1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a0[u] = n0[u];
+                a1[u] = n1[u];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            out[ti][e] = hprev[ti][e] > 0.f ? acc0[e] : 0.f;
+            if (STEP == 2) out[ti + 1][e] = hprev[ti + 1][e] > 0.f ? acc1[e] : 0.f;
+        }
     }
 }
 
@@ -195,6 +280,76 @@ __device__ __forceinline__ float dw_tile(const float* __restrict__ st, int arow,
     return asum;
 }
 
+// two dW tiles that share their B rows (A rows arow0 / arow1): independent accumulation chains, fragments fetched one
+// block (4 MFMA steps = 8 points) ahead
+__device__ __forceinline__ void dw_pair_a(const float* __restrict__ st, int arow0, int arow1, int brow, int r, int h,
+                                          f32x16& acc0, f32x16& acc1, float& asum0, float& asum1) {
+    const float* a0p = st + (arow0 + r) * LDS_ST + 4 * h;
+    const float* a1p = st + (arow1 + r) * LDS_ST + 4 * h;
+    const float* bp = st + (brow + r) * LDS_ST + 4 * h;
+    constexpr int NQ = kStagePts / 8;
+    float4 a0 = *reinterpret_cast<const float4*>(a0p), a1 = *reinterpret_cast<const float4*>(a1p);
+    float4 b = *reinterpret_cast<const float4*>(bp);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        float4 na0 = a0, na1 = a1, nb = b;
+        if (q + 1 < NQ) {
+            na0 = *reinterpret_cast<const float4*>(a0p + 8 * (q + 1));
+            na1 = *reinterpret_cast<const float4*>(a1p + 8 * (q + 1));
+            nb = *reinterpret_cast<const float4*>(bp + 8 * (q + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = mfma(a0.x, b.x, acc0);
+        acc1 = mfma(a1.x, b.x, acc1);
+        acc0 = mfma(a0.y, b.y, acc0);
+        acc1 = mfma(a1.y, b.y, acc1);
+        acc0 = mfma(a0.z, b.z, acc0);
+        acc1 = mfma(a1.z, b.z, acc1);
+        acc0 = mfma(a0.w, b.w, acc0);
+        acc1 = mfma(a1.w, b.w, acc1);
+        asum0 += (a0.x + a0.y) + (a0.z + a0.w);
+        asum1 += (a1.x + a1.y) + (a1.z + a1.w);
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = na0;
+        a1 = na1;
+        b = nb;
+    }
+}
+
+// two dW tiles that share their A rows (B rows brow0 / brow1)
+__device__ __forceinline__ void dw_pair_b(const float* __restrict__ st, int arow, int brow0, int brow1, int r, int h,
+                                          f32x16& acc0, f32x16& acc1, float& asum) {
+    const float* ap = st + (arow + r) * LDS_ST + 4 * h;
+    const float* b0p = st + (brow0 + r) * LDS_ST + 4 * h;
+    const float* b1p = st + (brow1 + r) * LDS_ST + 4 * h;
+    constexpr int NQ = kStagePts / 8;
+    float4 a = *reinterpret_cast<const float4*>(ap);
+    float4 b0 = *reinterpret_cast<const float4*>(b0p), b1 = *reinterpret_cast<const float4*>(b1p);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        float4 na = a, nb0 = b0, nb1 = b1;
+        if (q + 1 < NQ) {
+            na = *reinterpret_cast<const float4*>(ap + 8 * (q + 1));
+            nb0 = *reinterpret_cast<const float4*>(b0p + 8 * (q + 1));
+            nb1 = *reinterpret_cast<const float4*>(b1p + 8 * (q + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = mfma(a.x, b0.x, acc0);
+        acc1 = mfma(a.x, b1.x, acc1);
+        acc0 = mfma(a.y, b0.y, acc0);
+        acc1 = mfma(a.y, b1.y, acc1);
+        acc0 = mfma(a.z, b0.z, acc0);
+        acc1 = mfma(a.z, b1.z, acc1);
+        acc0 = mfma(a.w, b0.w, acc0);
+        acc1 = mfma(a.w, b1.w, acc1);
+        asum += (a.x + a.y) + (a.z + a.w);
+        __builtin_amdgcn_sched_barrier(0);
+        a = na;
+        b0 = nb0;
+        b1 = nb1;
+    }
+}
+
 // stage row groups
 constexpr int RA_GY = 0, RA_H4 = 4, RA_D4 = RA_H4 + C4, RA_H3 = RA_D4 + C4;   // group A: 260 rows
 constexpr int RB_D3 = 0, RB_H2 = C3;                                          // group B: 192 rows
@@ -207,7 +362,7 @@ __global__ __launch_bounds__(256, 1) void target_bwd_kernel(int N, int iters, co
     __shared__ __attribute__((aligned(16))) float lds[kBwdLds];
     float* st = lds + kWFloats;
     const int cloud = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    load_theta(theta + (long)cloud * theta_ld, lds, tid, 256);
+    load_theta<256>(theta + (long)cloud * theta_ld, lds, tid);
     const float* P = pts + (long)cloud * N * 3;
     const float* G = gy + (long)cloud * N * 3;
 
@@ -266,12 +421,7 @@ __global__ __launch_bounds__(256, 1) void target_bwd_kernel(int N, int iters, co
                 stage_put<4>(st, RA_H3, h3, pl, h);
             }
             __syncthreads();
-            const float s0 = dw_tile<false, false>(st, RA_D4, RA_H3 + wave * 32, r, h, acc4[0]);
-            const float s1 = dw_tile<false, false>(st, RA_D4 + 32, RA_H3 + wave * 32, r, h, acc4[1]);
-            if (wave == 0) {
-                db4[0] += s0;
-                db4[1] += s1;
-            }
+            dw_pair_a(st, RA_D4, RA_D4 + 32, RA_H3 + wave * 32, r, h, acc4[0], acc4[1], db4[0], db4[1]);   // db4: wave 0's copy is stored
             if (wave >= 2) {
                 const float s5 = dw_tile<true, false>(st, RA_GY, RA_H4 + (wave - 2) * 32, r, h, accs, 3);
                 if (wave == 2) dbs += s5;
@@ -289,8 +439,7 @@ __global__ __launch_bounds__(256, 1) void target_bwd_kernel(int N, int iters, co
                 stage_put<2>(st, RB_H2, h2, pl, h);
             }
             __syncthreads();
-            db3 += dw_tile<false, false>(st, RB_D3 + wave * 32, RB_H2, r, h, acc3[0]);
-            (void)dw_tile<false, false>(st, RB_D3 + wave * 32, RB_H2 + 32, r, h, acc3[1]);
+            dw_pair_b(st, RB_D3 + wave * 32, RB_H2, RB_H2 + 32, r, h, acc3[0], acc3[1], db3);
         }
 
         // ---- delta2, delta1, group C: dW2 (+db2), dW1|db1
@@ -378,7 +527,7 @@ __global__ __launch_bounds__(256) void target_reduce_kernel(int S, const float* 
 // workgroups per cloud for the backward: enough to cover the chip, each at least one 128-point iteration
 int bwd_splits(int B, int N) {
     const int blocks = (N + 127) / 128;
-    int s = (512 + B - 1) / B;
+    int s = (256 + B - 1) / B;                          // one resident workgroup per CU (147 KB of LDS each)
     if (s > blocks) s = blocks;
     if (s > 16) s = 16;
     return s < 1 ? 1 : s;
@@ -396,7 +545,7 @@ HP_API long hp_target_fused_workspace_floats(int B, int N) { return (long)B * bw
 HP_API int hp_target_fused_forward(int B, int N, const float* theta, int theta_ld, const float* pts, float* y, hipStream_t stream) {
     HP_CHECK_ARG(B > 0 && B <= 65535 && N > 0 && theta && pts && y && theta_ld >= kTheta);
     const int blocks = (N + 255) / 256;
-    int per = (blocks * B + 1023) / 1024;              // ~2 rounds of 2 workgroups per CU
+    int per = (blocks * B + 255) / 256;                // one resident workgroup per CU: theta is staged once per CU
     if (per < 1) per = 1;
     const int gx = (blocks + per - 1) / per;
     hipLaunchKernelGGL(target_fwd_kernel, dim3(gx, B), dim3(512), 0, stream, N, per, theta, theta_ld, pts, y);
