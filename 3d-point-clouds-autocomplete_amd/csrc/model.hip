@@ -182,8 +182,9 @@ __global__ __launch_bounds__(256) void gather_rows3_kernel(const float* __restri
     xc[t * 3 + 2] = s[2];
 }
 
-// One workgroup per critical row t = (b, c): copies the row's x (3), h1 (64), h2 (128), h3 (256), h4 (512) out of
-// the forward's per-point activation arrays (source row b*Np + arg[t]) with 16-byte accesses.
+// One workgroup per critical row t = (b, c): copies the row's x (3), h1 (64), h2 (128), h3 (256) and — unless c4 is
+// NULL: its only reader, the layer-5 kernel, can index the forward's array itself — h4 (512) out of the forward's
+// per-point activation arrays (source row b*Np + arg[t]) with 16-byte accesses.
 __global__ __launch_bounds__(256) void gather_critical_kernel(int Np, const int* __restrict__ arg, const float* __restrict__ x,
                                                               const float* __restrict__ h1, const float* __restrict__ h2,
                                                               const float* __restrict__ h3, const float* __restrict__ h4,
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256) void gather_critical_kernel(int Np, const int*
     } else if (i < 112) {
         reinterpret_cast<float4*>(c3 + t * 256)[i - 48] = reinterpret_cast<const float4*>(h3 + src * 256)[i - 48];
     } else if (i < 240) {
-        reinterpret_cast<float4*>(c4 + t * 512)[i - 112] = reinterpret_cast<const float4*>(h4 + src * 512)[i - 112];
+        if (c4) reinterpret_cast<float4*>(c4 + t * 512)[i - 112] = reinterpret_cast<const float4*>(h4 + src * 512)[i - 112];
     } else if (i < 243) {
         xc[t * 3 + (i - 240)] = x[src * 3 + (i - 240)];
     }
@@ -212,9 +213,12 @@ __global__ __launch_bounds__(256) void gather_critical_kernel(int Np, const int*
 //   db5[c]         = sum_b dg[b,c]
 // One workgroup per channel c; K % 4 == 0.  Thread (q = tid & 127, g = tid >> 7) owns 4 consecutive k and the
 // clouds b = g, g + 2, ...; the two b-halves are combined through LDS in a fixed order.
+// h4c: the critical rows' h4, row (b,c) at h4c + (b*C + c)*K — or, with arg != NULL, the forward's full h4 with row
+// (b,c) at h4c + (b*Np + arg[b*C + c])*K (no gathered copy of the widest activation is ever made).
 __global__ __launch_bounds__(256) void enc_l5_bwd_kernel(int B, int C, int K, const float* __restrict__ dg,
                                                          const float* __restrict__ W5, const float* __restrict__ h4c,
-                                                         float* __restrict__ dW5, float* __restrict__ d4, float* __restrict__ db5) {
+                                                         const int* __restrict__ arg, int Np, float* __restrict__ dW5,
+                                                         float* __restrict__ d4, float* __restrict__ db5) {
     __shared__ float4 red[128];
     const int c = blockIdx.x;
     const int q = threadIdx.x & 127, g = threadIdx.x >> 7;
@@ -230,7 +234,8 @@ __global__ __launch_bounds__(256) void enc_l5_bwd_kernel(int B, int C, int K, co
         for (int b = g; b < B; b += 2) {
             const long row = (long)b * C + c;
             const float gbc = dg[row];
-            const float4 hv = *reinterpret_cast<const float4*>(h4c + row * K + k);
+            const long src = arg ? (long)b * Np + arg[row] : row;
+            const float4 hv = *reinterpret_cast<const float4*>(h4c + src * K + k);
             s.x = __builtin_fmaf(gbc, hv.x, s.x);
             s.y = __builtin_fmaf(gbc, hv.y, s.y);
             s.z = __builtin_fmaf(gbc, hv.z, s.z);
@@ -381,7 +386,7 @@ static int enc_critical_rows(int B, int Np, const float* x, const HpEncoderWeigh
         const float* h3 = h2 + R * 128;
         const float* h4 = h3 + R * 256;
         hipLaunchKernelGGL(gather_critical_kernel, dim3((unsigned)Rc), dim3(256), 0, stream, Np, argidx, x, h1, h2, h3, h4, L.xc,
-                           L.hc[1], L.hc[2], L.hc[3], L.hc[4]);
+                           L.hc[1], L.hc[2], L.hc[3], (float*)nullptr);
         HP_RETURN_LAST_ERROR();
     }
     Op op{stream, nullptr};
@@ -432,7 +437,9 @@ HP_API int hp_encoder_backward(int B, int Np, const float* x, const HpEncoderWei
     TRY(op.lin_dx(dfc, 0, 512, w->fc_w, 0, dg, 0, 512, B, 512, 512, 1, nullptr, 0, 0, nullptr, 0));
 
     // ---- conv stack on the B*512 critical rows
-    hipLaunchKernelGGL(enc_l5_bwd_kernel, dim3(512), dim3(256), 0, stream, B, 512, 512, dg, w->conv_w[4], hc[4], gr->conv_w[4],
+    const float* h4_full = fwd_ws ? fwd_ws + (long)B * Np * (64 + 128 + 256) : nullptr;
+    hipLaunchKernelGGL(enc_l5_bwd_kernel, dim3(512), dim3(256), 0, stream, B, 512, 512, dg, w->conv_w[4],
+                       h4_full ? h4_full : hc[4], h4_full ? argidx : (const int*)nullptr, Np, gr->conv_w[4],
                        dl[4], gr->conv_b[4]);
     for (int l = 4; l >= 1; --l) {
         const float* below = l > 1 ? hc[l - 1] : xc;
