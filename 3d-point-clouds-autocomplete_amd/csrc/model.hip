@@ -46,7 +46,8 @@ int pick_ksplit(int outM, int outN, int kc, int batch) {
     if (tiles >= 512 || kc < 256) return 1;
     long ks = tiles >= 256 ? std::min<long>(cdiv(768, tiles), kc / 512)      // long skinny K loops (M = B heads GEMM)
                            : std::min<long>(cdiv(512, tiles), kc / 128);
-    ks = std::max<long>(1, std::min<long>(ks, 64));
+    // tiny outputs (dW1 = 64x3 over 32768 rows) take more, shorter slabs: the reduce kernel sums 16 slabs per round trip
+    ks = std::max<long>(1, std::min<long>(ks, (long)outM * outN * batch <= 8192 ? 128 : 64));
     while (ks > 1 && (long)outM * outN * batch * ks > kSplitWs) --ks;
     return (int)ks;
 }
