@@ -100,6 +100,9 @@ __global__ __launch_bounds__(WGM* WGN * 64, (BM == 128 && BN == 128) ? 4 : 1) vo
     constexpr int NA = (BM * KQ + NT - 1) / NT, NB = (BN * KQ + NT - 1) / NT;
     constexpr int AM = MODE % 3, BMD = MODE / 3;
     constexpr int RSTEP = NT / BK;             // loader 2: rows between a thread's consecutive elements
+    // The 128x128 tile runs at the 128-VGPR limit of 4 waves/SIMD: its loaders 0/1 carry no K-tail path (the host
+    // sends problems whose k-range is not whole k-tiles to the smaller tiles), which keeps it free of scratch spills.
+    constexpr bool TAILS = !(BM == 128 && BN == 128);
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
     static_assert(NT % BK == 0, "loader 2 keeps one k per thread");
     __shared__ __attribute__((aligned(16))) float As[BM * LDK];
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (BM == 128 && BN == 128) ? 4 : 1) vo
                 ra[e].w = ld_sel(pa[e] + 3 * a_ustep, A, kin && (a_ok >> (4 * e + 3) & 1));
                 pa[e] += BK;
             }
-        } else if (whole) {
+        } else if (whole || !TAILS) {
 #pragma unroll
             for (int e = 0; e < NA; ++e)
                 if (BM * KQ % NT == 0 || tid + e * NT < BM * KQ) {
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (BM == 128 && BN == 128) ? 4 : 1) vo
                 rb[e].w = ld_sel(pb[e] + 3 * b_ustep, B, kin && (b_ok >> (4 * e + 3) & 1));
                 pb[e] += BK;
             }
-        } else if (whole) {
+        } else if (whole || !TAILS) {
 #pragma unroll
             for (int e = 0; e < NB; ++e)
                 if (BN * KQ % NT == 0 || tid + e * NT < BN * KQ) {
@@ -528,7 +531,10 @@ int choose_cfg(const HpGemmDesc* d, int ksplit) {
     const long zs = (long)d->batch * ksplit;
     auto wgs = [&](int bm, int bn) { return (long)((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn) * zs; };
     if (d->N <= 32) return 0;
-    if (d->M > 64 && d->N > 64 && wgs(128, 128) >= 384) return 1;
+    // the 128x128 kernel has no K-tail path: whole 16-deep k-tiles per split only
+    // (split ranges start at multiples of 32, so K % 16 == 0 makes every range a whole number of k-tiles)
+    const bool whole_tiles = d->K >= 16 && d->K % 16 == 0;
+    if (whole_tiles && d->M > 64 && d->N > 64 && wgs(128, 128) >= 384) return 1;
     if (d->N > 64 && wgs(64, 128) >= 512) return 2;
     return 3;
 }
