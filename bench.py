@@ -73,7 +73,7 @@ def event_time_ms(fn, iters, warm=2):
 
 
 def roofline_dominant_kernel(batch, n_half):
-    """The kernel with the largest share of the step (profiles/): gemm_kernel<128,128,2,2,16,4>, the fp32-MFMA GEMM
+    """The kernel with the largest share of the step (profiles/): gemm_kernel<128,128,4,2,16,4>, the fp32-MFMA GEMM
     that runs the encoder's wide layers (M = B*1024 points).  One launch = layer 5 of one encoder:
     C(M x 512) = A(M x 512) W(512 x 512)^T + b.  Algorithmic flops = 2*M*512*512 (868 736 FLOP/point
     of which layer 5 is 2*512*512).  `traffic` (HBM bytes per launch) comes from the PMC passes recorded in
@@ -91,7 +91,7 @@ def roofline_dominant_kernel(batch, n_half):
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm_conv5.json")
     if os.path.exists(pmc) and batch == 64 and n_half == 1024:
         traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
-    return {"bound": "mfma", "kernel": "gemm_kernel<128,128,2,2,16,4> (encoder conv5: M=B*1024, N=K=512, fp32 MFMA 32x32x2)",
+    return {"bound": "mfma", "kernel": "gemm_kernel<128,128,4,2,16,4> (encoder conv5: M=B*1024, N=K=512, fp32 MFMA 32x32x2)",
             "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
             "avg_launch_ms": round(ms, 4), "flops_per_launch": flops,
