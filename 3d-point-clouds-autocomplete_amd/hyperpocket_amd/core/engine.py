@@ -17,6 +17,8 @@ from ..parallel import FlatParameters, GradientReducer
 
 
 class TrainEngine:
+    _DEFERRED = (1, 0)   # buckets whose exchange + update cross the step boundary when world > 1: trunk, heads
+
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, loss_coef=0.05, emd_coef=0.0, process_group=None):
         self.model = model
         self.lr, self.betas, self.eps = lr, betas, eps
@@ -57,18 +59,19 @@ class TrainEngine:
             self._install_overlap_hook()
         torch.autograd.backward(roots, root_grads)
         self.steps += 1
-        # Exchange + update per bucket.  Trunk and encoders (17 MB) are reduced and updated now; the hypernetwork heads
-        # (156 MB, 90 % of the bytes) are only needed again in the NEXT step's hypernetwork forward, which comes after
-        # ~1 ms of encoder forward: their all-reduce stays in flight across the step boundary and `finish_pending`
-        # (called by FullModel.forward right before the hypernetwork) waits for it and applies their Adam update there.
+        # Exchange + update per bucket.  The encoders' bucket (6.6 MB) is reduced and updated now: the next step starts
+        # with it.  The hypernetwork's buckets (heads 156 MB, trunk 11 MB: 96 % of the bytes) are only needed again in the
+        # NEXT step's hypernetwork forward, which comes after ~1 ms of encoder forward: their all-reduces stay in flight
+        # across the step boundary and `finish_pending` (called by FullModel.forward right before the hypernetwork)
+        # waits for them and applies their Adam updates there.
         self.reducer.launch_all()
-        for b in range(1, len(self.flat.buckets)):
-            self.reducer.wait(b)
-            self._adam(b)
-        if self.world > 1:
-            self._heads_pending = True
-        else:
-            self._adam(0)
+        nb = len(self.flat.buckets)
+        deferred = self._DEFERRED if self.world > 1 else ()
+        for b in range(nb - 1, -1, -1):
+            if b not in deferred:
+                self.reducer.wait(b)
+                self._adam(b)
+        self._heads_pending = bool(deferred)
         return out
 
     def _losses_and_gradients(self, gt, rec_n3, logvar, mu):
@@ -157,10 +160,12 @@ class TrainEngine:
                       self.betas[0], self.betas[1], self.eps, self.steps)
 
     def finish_pending(self):
-        """Complete the deferred heads update (idempotent).  Call before reading the parameters outside `step`."""
+        """Complete the deferred hypernetwork updates (idempotent).  Call before reading the parameters outside `step`."""
         if self._heads_pending:
-            self.reducer.wait(0)
-            self._adam(0)
+            for b in self._DEFERRED:
+                if b < len(self.flat.buckets):
+                    self.reducer.wait(b)
+                    self._adam(b)
             self._heads_pending = False
 
     def _install_overlap_hook(self):
