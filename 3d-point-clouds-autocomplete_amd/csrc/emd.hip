@@ -161,7 +161,9 @@ __global__ __launch_bounds__(kThreads) void emd_rows1_kernel(Ctx c, int lev1, fl
         if (DO3) rl = ratioL[k];
     }
     const f2 px2 = splat(px), py2 = splat(py), pz2 = splat(pz), rl2 = splat(rl), l3 = splat(l2e3), l1 = splat(l2e1);
-    float acc3 = 0.f, acc1 = part == 0 ? 1e-9f : 0.f;
+    // even / odd candidates accumulate in the two halves of a packed register (one v_pk_add_f32 per pair record instead
+    // of two dependent v_add_f32); the halves are added once at the end, then the 4 candidate ranges in range order
+    f2 acc3 = splat(0.f), acc1 = f2{part == 0 ? 1e-9f : 0.f, 0.f};
     const int cand = c.MP / kParts;                                  // candidates of this wave's range
     const float* p = ws + c.prp + (long)part * cand * 4;   // wave-uniform
     const float* q = ws + c.rr + (long)part * cand;
@@ -172,14 +174,10 @@ __global__ __launch_bounds__(kThreads) void emd_rows1_kernel(Ctx c, int lev1, fl
         for (int u = 0; u < kStage / 2; ++u) {
             const f2 d = sqdist2(PAIRC(lo, hi, u, 0) - px2, PAIRC(lo, hi, u, 1) - py2, PAIRC(lo, hi, u, 2) - pz2);
             if (DO3) {
-                const f2 t = (exp2_2(l3 * d) * rl2) * PAIRC(lo, hi, u, 3);   // (e * ratioL[k]) * ratioR[l]
-                acc3 += t.x;
-                acc3 += t.y;
+                acc3 += (exp2_2(l3 * d) * rl2) * PAIRC(lo, hi, u, 3);   // (e * ratioL[k]) * ratioR[l]
             }
             if (DO1) {
-                const f2 t = exp2_2(l1 * d) * f2{w[u * 2], w[u * 2 + 1]};   // e * remainR[l]
-                acc1 += t.x;
-                acc1 += t.y;
+                acc1 += exp2_2(l1 * d) * f2{w[u * 2], w[u * 2 + 1]};   // e * remainR[l]
             }
         }
     };
@@ -205,22 +203,23 @@ __global__ __launch_bounds__(kThreads) void emd_rows1_kernel(Ctx c, int lev1, fl
         work(b0, b1, w1);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+s"(w0), "+v"(acc3), "+v"(acc1));
     }
-    part3[part][lrow] = acc3;
-    part1[part][lrow] = acc1;
+    float s3 = acc3.x + acc3.y, s1 = acc1.x + acc1.y;
+    part3[part][lrow] = s3;
+    part1[part][lrow] = s1;
     __syncthreads();
     if (part != 0 || !ok) return;
 #pragma unroll
     for (int q2 = 1; q2 < kParts; ++q2) {
-        acc3 += part3[q2][lrow];
-        acc1 += part1[q2][lrow];
+        s3 += part3[q2][lrow];
+        s1 += part1[q2][lrow];
     }
     float rem = remL[k];
     if (DO3) {
-        rem = fmaxf(0.0f, rem - acc3);
+        rem = fmaxf(0.0f, rem - s3);
         remL[k] = rem;
     }
     if (DO1) {
-        const float v = rem / acc1;
+        const float v = rem / s1;
         ratioL[k] = v;
         ws[c.plp + pair8(k, 3)] = v;
         ws[c.flp + pair32(k, 3 + lev1)] = v;
@@ -246,7 +245,7 @@ __global__ __launch_bounds__(kThreads) void emd_rows2_kernel(Ctx c, int lev, flo
         qz = s[2];
     }
     const f2 qx2 = splat(qx), qy2 = splat(qy), qz2 = splat(qz), lv = splat(l2e);
-    float acc = 0.f;
+    f2 acc2 = splat(0.f);   // even / odd candidates (see emd_rows1_kernel)
     const int cand = c.NP / kParts;
     const float* p = ws + c.plp + (long)part * cand * 4;
     f32x16 a0, a1, b0, b1;
@@ -255,9 +254,7 @@ __global__ __launch_bounds__(kThreads) void emd_rows2_kernel(Ctx c, int lev, flo
         for (int u = 0; u < kStage / 2; ++u) {
             // the reference evaluates (x2-x1) with x2 the set2 point in every phase (approxmatch.cu:85,131,185)
             const f2 d = sqdist2(qx2 - PAIRC(lo, hi, u, 0), qy2 - PAIRC(lo, hi, u, 1), qz2 - PAIRC(lo, hi, u, 2));
-            const f2 t = exp2_2(lv * d) * PAIRC(lo, hi, u, 3);
-            acc += t.x;
-            acc += t.y;
+            acc2 += exp2_2(lv * d) * PAIRC(lo, hi, u, 3);
         }
     };
     HP_SLOAD16(a0, p, 0x0);
@@ -269,14 +266,15 @@ __global__ __launch_bounds__(kThreads) void emd_rows2_kernel(Ctx c, int lev, flo
         HP_SLOAD16(b1, p, 0x40);
         HP_PIN();
         work(a0, a1);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1), "+v"(acc));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1), "+v"(acc2));
         p += kStage * 4;
         HP_SLOAD16(a0, p, 0x0);
         HP_SLOAD16(a1, p, 0x40);
         HP_PIN();
         work(b0, b1);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(acc));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(acc2));
     }
+    float acc = acc2.x + acc2.y;
     parts[part][lrow] = acc;
     __syncthreads();
     if (part != 0 || !ok) return;
@@ -375,20 +373,16 @@ __global__ __launch_bounds__(kThreads) void emd_cost_grad1_kernel(Ctx c, float* 
     float px = 0.f, py = 0.f, pz = 0.f, rL[kLevels] = {};
     if (ok) load_row_final(ws + c.flp, k, px, py, pz, rL);
     const f2 px2 = splat(px), py2 = splat(py), pz2 = splat(pz);
-    float cost = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+    f2 cost2 = splat(0.f), dx2 = splat(0.f), dy2 = splat(0.f), dz2 = splat(0.f);   // even / odd candidates (see emd_rows1_kernel)
     auto work = [&](const f32x16& lo, const f32x16& hi) {
         const f2 ex = px2 - FINC(lo, hi, 0), ey = py2 - FINC(lo, hi, 1), ez = pz2 - FINC(lo, hi, 2);   // (x1 - x2), approxmatch.cu:312
         const f2 d2 = sqdist2(ex, ey, ez);       // squares: the sign of the difference does not change a bit
         const f2 mv = match_entry2<true>(d2, rL, lo, hi);
         const f2 w = mv * f2{__builtin_amdgcn_rsqf(fmaxf(d2.x, 1e-20f)), __builtin_amdgcn_rsqf(fmaxf(d2.y, 1e-20f))};
-        cost = __builtin_fmaf(mv.x, __builtin_amdgcn_sqrtf(d2.x), cost);
-        cost = __builtin_fmaf(mv.y, __builtin_amdgcn_sqrtf(d2.y), cost);
-        dx = __builtin_fmaf(ex.x, w.x, dx);
-        dx = __builtin_fmaf(ex.y, w.y, dx);
-        dy = __builtin_fmaf(ey.x, w.x, dy);
-        dy = __builtin_fmaf(ey.y, w.y, dy);
-        dz = __builtin_fmaf(ez.x, w.x, dz);
-        dz = __builtin_fmaf(ez.y, w.y, dz);
+        cost2 = __builtin_elementwise_fma(mv, f2{__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)}, cost2);
+        dx2 = __builtin_elementwise_fma(ex, w, dx2);
+        dy2 = __builtin_elementwise_fma(ey, w, dy2);
+        dz2 = __builtin_elementwise_fma(ez, w, dz2);
     };
     const int cand = c.MP / kParts;
     const float* p = ws + c.frp + (long)part * cand * 16;
@@ -402,14 +396,15 @@ __global__ __launch_bounds__(kThreads) void emd_cost_grad1_kernel(Ctx c, float* 
         HP_SLOAD16(b1, p, 0x40);
         HP_PIN();
         work(a0, a1);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1), "+v"(cost), "+v"(dx), "+v"(dy), "+v"(dz));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1), "+v"(cost2), "+v"(dx2), "+v"(dy2), "+v"(dz2));
         p += 32;
         HP_SLOAD16(a0, p, 0x0);
         HP_SLOAD16(a1, p, 0x40);
         HP_PIN();
         work(b0, b1);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(cost), "+v"(dx), "+v"(dy), "+v"(dz));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(cost2), "+v"(dx2), "+v"(dy2), "+v"(dz2));
     }
+    float cost = cost2.x + cost2.y, dx = dx2.x + dx2.y, dy = dy2.x + dy2.y, dz = dz2.x + dz2.y;
     parts[part][0][lrow] = dx;
     parts[part][1][lrow] = dy;
     parts[part][2][lrow] = dz;
@@ -450,22 +445,17 @@ __global__ __launch_bounds__(kThreads) void emd_grad2_kernel(Ctx c, float* __res
     float qx = 0.f, qy = 0.f, qz = 0.f, rR[kLevels] = {};
     if (ok) load_row_final(ws + c.frp, l, qx, qy, qz, rR);
     const f2 qx2 = splat(qx), qy2 = splat(qy), qz2 = splat(qz);
-    float sx = 0.f, sy = 0.f, sz = 0.f, cost = 0.f;
+    f2 sx2 = splat(0.f), sy2 = splat(0.f), sz2 = splat(0.f), cost2 = splat(0.f);   // even / odd candidates (see emd_rows1_kernel)
     auto work = [&](const f32x16& lo, const f32x16& hi) {
         const f2 ex = qx2 - FINC(lo, hi, 0), ey = qy2 - FINC(lo, hi, 1), ez = qz2 - FINC(lo, hi, 2);
         const f2 d2 = sqdist2(ex, ey, ez);
         const f2 mv = match_entry2<false>(d2, rR, lo, hi);
         const f2 w = mv * f2{__builtin_amdgcn_rsqf(fmaxf(d2.x, 1e-20f)), __builtin_amdgcn_rsqf(fmaxf(d2.y, 1e-20f))};
-        if (WITH_COST) {
-            cost = __builtin_fmaf(mv.x, __builtin_amdgcn_sqrtf(d2.x), cost);
-            cost = __builtin_fmaf(mv.y, __builtin_amdgcn_sqrtf(d2.y), cost);
-        }
-        sx = __builtin_fmaf(ex.x, w.x, sx);
-        sx = __builtin_fmaf(ex.y, w.y, sx);
-        sy = __builtin_fmaf(ey.x, w.x, sy);
-        sy = __builtin_fmaf(ey.y, w.y, sy);
-        sz = __builtin_fmaf(ez.x, w.x, sz);
-        sz = __builtin_fmaf(ez.y, w.y, sz);
+        if (WITH_COST)
+            cost2 = __builtin_elementwise_fma(mv, f2{__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)}, cost2);
+        sx2 = __builtin_elementwise_fma(ex, w, sx2);
+        sy2 = __builtin_elementwise_fma(ey, w, sy2);
+        sz2 = __builtin_elementwise_fma(ez, w, sz2);
     };
     const int cand = c.NP / kParts;
     const float* p = ws + c.flp + (long)part * cand * 16;
@@ -479,14 +469,15 @@ __global__ __launch_bounds__(kThreads) void emd_grad2_kernel(Ctx c, float* __res
         HP_SLOAD16(b1, p, 0x40);
         HP_PIN();
         work(a0, a1);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1), "+v"(sx), "+v"(sy), "+v"(sz), "+v"(cost));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1), "+v"(sx2), "+v"(sy2), "+v"(sz2), "+v"(cost2));
         p += 32;
         HP_SLOAD16(a0, p, 0x0);
         HP_SLOAD16(a1, p, 0x40);
         HP_PIN();
         work(b0, b1);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(sx), "+v"(sy), "+v"(sz), "+v"(cost));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(sx2), "+v"(sy2), "+v"(sz2), "+v"(cost2));
     }
+    float sx = sx2.x + sx2.y, sy = sy2.x + sy2.y, sz = sz2.x + sz2.y, cost = cost2.x + cost2.y;
     parts[part][0][lrow] = sx;
     parts[part][1][lrow] = sy;
     parts[part][2][lrow] = sz;
