@@ -94,6 +94,16 @@ class TrainEngine:
             self._consts[dev] = (torch.full((), float(self.loss_coef), **f32), torch.ones((), **f32))
         c_cd, one = self._consts[dev]
         cur = torch.cuda.current_stream(dev)
+        # Everything that outlives the side-stream section is allocated here, on the compute stream: the join below orders
+        # the two streams, so no tensor needs record_stream() — each of those costs a hipEventRecord on the compute
+        # queue when the block is freed, i.e. a ~5 us bubble between two kernels.
+        cd = torch.empty((), **f32)
+        g_rec = torch.empty_like(rec_c)
+        kld = g_lv = g_mu = lv_c = mu_c = None
+        if has_kld:
+            lv_c, mu_c = logvar.contiguous(), mu.contiguous()
+            kld = torch.empty((), **f32)
+            g_lv, g_mu = torch.empty_like(lv_c), torch.empty_like(mu_c)
         side = None
         if self.emd_coef:
             # Chamfer / KLD (VALU-bound, ~0.15 ms) and the EMD sweeps (2 waves/SIMD, VALU pipe ~60 % busy) are
@@ -102,28 +112,20 @@ class TrainEngine:
             from ..model.full_model import _side_stream
             side = _side_stream(model, dev)
             side.wait_stream(cur)
-            for t in (gt_c, rec_c, logvar, mu):
-                if t is not None:
-                    t.record_stream(side)
         with torch.cuda.stream(side if side is not None else cur):
             st = current_stream(dev)
-            dist1, dist2 = torch.empty((B, N), **f32), torch.empty((B, N), **f32)
+            dist1, dist2 = torch.empty((B, N), **f32), torch.empty((B, N), **f32)      # temporaries of this section
             idx1 = torch.empty((B, N), dtype=torch.int32, device=dev)
             idx2 = torch.empty((B, N), dtype=torch.int32, device=dev)
             part = torch.empty((lib.hp_chamfer_workspace_floats(B, N, N),), **f32)
-            cd = torch.empty((), **f32)
-            g_rec = torch.empty_like(rec_c)
             # ChamferLoss()(gt, reconstruction): losses/champfer_loss.py:11-17 with preds = gt (core/epoch_loops.py:26)
             call("hp_chamfer_forward", B, N, gt_c, N, rec_c, dist1, idx1, dist2, idx2, part, cd, st)
             call("hp_chamfer_backward", B, N, gt_c, N, rec_c, idx1, idx2, c_cd, None, g_rec, st)
-            kld = g_lv = g_mu = None
             if has_kld:
-                lv_c, mu_c = logvar.contiguous(), mu.contiguous()
-                kld = torch.empty((), **f32)
-                g_lv, g_mu = torch.empty_like(lv_c), torch.empty_like(mu_c)
                 n_el, batch = ctypes.c_long(mu_c.numel()), B * self.world
                 call("hp_kld_forward", n_el, batch, lv_c, mu_c, kld, st)
                 call("hp_kld_backward", n_el, batch, lv_c, mu_c, one, g_lv, g_mu, st)
+            del dist1, dist2, idx1, idx2, part
         cost = None
         c_emd = 0.0
         if self.emd_coef:
@@ -137,10 +139,7 @@ class TrainEngine:
             # match_cost(gt, reconstruction): cost and d cost / d reconstruction from the same sweeps
             call("hp_emd_forward", B, N, N, gt_c, rec_c, temp, ws, epart, cost, None, g_emd, current_stream(dev))
             cur.wait_stream(side)
-            for t in (cd, g_rec, kld, g_lv, g_mu):
-                if t is not None:
-                    t.record_stream(cur)
-            g_rec = torch.add(g_rec, g_emd, alpha=c_emd)
+            g_rec.add_(g_emd, alpha=c_emd)
         terms = torch.empty((4,), **f32)
         call("hp_step_losses", B, cd, kld, cost, float(self.loss_coef), c_emd, terms, current_stream(dev))
         out = {"loss_r": terms[0], "loss_all": terms[3]}
