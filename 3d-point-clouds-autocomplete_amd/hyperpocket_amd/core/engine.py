@@ -64,14 +64,16 @@ class TrainEngine:
         # NEXT step's hypernetwork forward, which comes after ~1 ms of encoder forward: their all-reduces stay in flight
         # across the step boundary and `finish_pending` (called by FullModel.forward right before the hypernetwork)
         # waits for them and applies their Adam updates there.
+        if self.world == 1:
+            self._adam_range(0, self.flat.total)     # nothing to exchange: one pass over the whole flat buffer
+            self._heads_pending = False
+            return out
         self.reducer.launch_all()
-        nb = len(self.flat.buckets)
-        deferred = self._DEFERRED if self.world > 1 else ()
-        for b in range(nb - 1, -1, -1):
-            if b not in deferred:
+        for b in range(len(self.flat.buckets) - 1, -1, -1):
+            if b not in self._DEFERRED:
                 self.reducer.wait(b)
                 self._adam(b)
-        self._heads_pending = bool(deferred)
+        self._heads_pending = True
         return out
 
     def _losses_and_gradients(self, gt, rec_n3, logvar, mu):
@@ -154,7 +156,9 @@ class TrainEngine:
         return roots, grads, out
 
     def _adam(self, bucket):
-        lo, hi = self.flat.buckets[bucket]
+        self._adam_range(*self.flat.buckets[bucket])
+
+    def _adam_range(self, lo, hi):
         ops.adam_step(self.flat.flat[lo:hi], self.flat.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.lr,
                       self.betas[0], self.betas[1], self.eps, self.steps)
 
