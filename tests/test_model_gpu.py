@@ -227,6 +227,58 @@ def test_target_network_forward_backward_vs_oracle(ref, fused, B, N):
         ops.FUSED_TARGET_NETWORK = True
 
 
+def test_target_fused_c_abi_padded_theta_rows_and_determinism(ref):
+    """hp_target_fused_forward/backward straight through the C ABI with theta rows padded (theta_ld > 19011, what a
+    caller slicing a wider buffer hands over): the padding is neither read into the result nor written, and the
+    backward (per-workgroup partials added in order) is bit-identical run to run."""
+    import ctypes
+    from hyperpocket_amd._lib import call, current_stream, load_library
+    lib = load_library()
+    lib.hp_target_fused_workspace_floats.restype = ctypes.c_long
+    B, N, T, LD = 3, 700, 19011, 19011 + 13
+    g = torch.Generator().manual_seed(21)
+    theta = torch.randn(B, T, generator=g) * 0.2
+    pts = torch.rand(B, N, 3, generator=g) * 2 - 1
+    gy = torch.randn(B, N, 3, generator=g)
+    wide = torch.full((B, LD), float("nan"))
+    wide[:, :T] = theta
+    wide_d, pts_d, gy_d = wide.cuda(), pts.cuda(), gy.cuda()
+    y = torch.empty(B, N, 3, device="cuda")
+    st = current_stream(y.device)
+    call("hp_target_fused_forward", B, N, wide_d, LD, pts_d, y, st)
+    th_r = theta.clone().requires_grad_(True)
+    ry = torch.stack([ref.target_forward(th_r[j], pts[j]) for j in range(B)])
+    close(y, ry, rtol=1e-5, atol=1e-5)
+    (ry * gy).sum().backward()
+    ws = torch.empty(lib.hp_target_fused_workspace_floats(B, N), device="cuda")
+    outs = []
+    for _ in range(3):
+        gth = torch.full((B, LD), 7.0, device="cuda")
+        call("hp_target_fused_backward", B, N, wide_d, LD, pts_d, gy_d, gth, ws, st)
+        outs.append(gth)
+    grad_close(outs[0][:, :T], th_r.grad, tol=2e-5)
+    assert torch.all(outs[0][:, T:] == 7.0)                       # padding untouched
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_step_losses_kernel():
+    """hp_step_losses: the four scalar terms of the engine's step in one launch."""
+    from hyperpocket_amd._lib import call, current_stream
+    g = torch.Generator().manual_seed(2)
+    cost = torch.rand(37, generator=g) * 100
+    cd, kld = torch.tensor(1234.5), torch.tensor(0.75)
+    out = torch.empty(4, device="cuda")
+    call("hp_step_losses", 37, cd.cuda(), kld.cuda(), cost.cuda(), 0.05, 0.05 / 2048, out, current_stream(out.device))
+    want_emd = (0.05 / 2048) * cost.double().sum().item()
+    got = out.cpu().double()
+    assert abs(got[0].item() - 0.05 * 1234.5) <= 1e-5 * 61.7
+    assert got[1].item() == 0.75
+    assert abs(got[2].item() - want_emd) <= 1e-6 * want_emd
+    assert abs(got[3].item() - (0.05 * 1234.5 + 0.75 + want_emd)) <= 1e-5 * 63
+    call("hp_step_losses", 0, cd.cuda(), None, None, 0.05, 0.0, out, current_stream(out.device))
+    assert out[1].item() == 0.0 and out[2].item() == 0.0 and abs(out[3].item() - out[0].item()) == 0.0
+
+
 def test_target_network_other_architecture_uses_layered_path(ref):
     """An architecture the fused kernels are not written for goes through the batched GEMMs."""
     from hyperpocket_amd.model.target_network import target_network_batched
