@@ -58,6 +58,8 @@ struct KParams {
     float* rsum;
     long sRsumz;
     long ws_rsum_off;   // offset (floats) of the row-sum partials inside ws when ksplit > 1
+    const int* dyn;     // device-side row count (see HpGemmDesc::dyn_count), or NULL
+    int dyn_kind;       // 1: it bounds M, 2: it bounds K
 };
 
 __device__ __forceinline__ float4 ld4(const float* __restrict__ base, long rowoff, int k, long s_k, bool row_ok, int kend, bool vec) {
@@ -119,7 +121,21 @@ __global__ __launch_bounds__(WGM* WGN * 64, (BM >= 128 && BN >= 128) ? ((BM / WG
     const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
     const int z = blockIdx.y / p.ksplit, split = blockIdx.y - z * p.ksplit;
     const int row0 = tile_m * BM, col0 = tile_n * BN;
-    const int kbeg = split * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
+    // sizes known only on the device (the encoder backward's compacted critical rows): M or K shrinks to *dyn; the grid
+    // was sized for the static bound, surplus row tiles leave at once and the split ranges re-partition the real K
+    int M = p.M, K = p.K, kchunk = p.kchunk;
+    if (p.dyn) {
+        const int v = *p.dyn;
+        if (p.dyn_kind == 1) {
+            M = min(M, v);
+        } else {
+            K = min(K, v);
+            kchunk = (((K + p.ksplit - 1) / p.ksplit + kMaxBK - 1) / kMaxBK) * kMaxBK;
+            if (kchunk == 0) kchunk = kMaxBK;
+        }
+        if (row0 >= M) return;
+    }
+    const int kbeg = split * kchunk, kend = min(K, kbeg + kchunk);
 
     const float* A = p.A + (long)z * p.sAz;
     const float* B = p.B + (long)z * p.sBz;
@@ -163,17 +179,17 @@ __global__ __launch_bounds__(WGM* WGN * 64, (BM >= 128 && BN >= 128) ? ((BM / WG
     if (AM == 2) {
 #pragma unroll
         for (int e = 0; e < NA; ++e) {
-            pa[e] = A + (long)min(row0 + r2 + 4 * e * RSTEP, p.M - 1) * p.sAi + (kbeg + k2);
+            pa[e] = A + (long)min(row0 + r2 + 4 * e * RSTEP, M - 1) * p.sAi + (kbeg + k2);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int row = r2 + (4 * e + u) * RSTEP;
-                if (row < BM && row0 + row < p.M) a_ok |= 1u << (4 * e + u);
+                if (row < BM && row0 + row < M) a_ok |= 1u << (4 * e + u);
             }
         }
     } else {
 #pragma unroll
         for (int e = 0; e < NA; ++e)
-            pa[e] = A + (long)min(row0 + a_row[e], p.M - 1) * p.sAi + (long)(kbeg + a_kq[e] * 4) * p.sAk;
+            pa[e] = A + (long)min(row0 + a_row[e], M - 1) * p.sAi + (long)(kbeg + a_kq[e] * 4) * p.sAk;
     }
     if (BMD == 2) {
 #pragma unroll
@@ -218,7 +234,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (BM >= 128 && BN >= 128) ? ((BM / WG
 #pragma unroll
             for (int e = 0; e < NA; ++e) {
                 const int row = row0 + a_row[e];
-                const bool ok = (tid + e * NT < BM * KQ) && row < p.M;
+                const bool ok = (tid + e * NT < BM * KQ) && row < M;
                 ra[e] = ld4(A, (long)row * p.sAi, k0 + a_kq[e] * 4, p.sAk, ok, kend, p.vecA);
             }
         }
@@ -328,7 +344,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (BM >= 128 && BN >= 128) ? ((BM / WG
         __syncthreads();
     }
 
-    if ((p.flags & HP_GEMM_ROWSUM) && tile_n == 0 && tid < BM && row0 + tid < p.M) {
+    if ((p.flags & HP_GEMM_ROWSUM) && tile_n == 0 && tid < BM && row0 + tid < M) {
         if (p.ksplit > 1) p.ws[p.ws_rsum_off + (long)blockIdx.y * p.M + row0 + tid] = rowsum;
         else p.rsum[(long)z * p.sRsumz + row0 + tid] = rowsum;
     }
@@ -398,7 +414,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (BM >= 128 && BN >= 128) ? ((BM / WG
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = row0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row >= p.M) continue;
+                if (row >= M) continue;
                 float v = acc[i][j][e];
                 if (!partial) {
                     v += bv;
@@ -547,7 +563,7 @@ int choose_cfg(const HpGemmDesc* d, int ksplit) {
     if (d->N <= 32) return 0;
     // the 128x128 kernel has no K-tail path: whole 16-deep k-tiles per split only
     // (split ranges start at multiples of 32, so K % 16 == 0 makes every range a whole number of k-tiles)
-    const bool whole_tiles = d->K >= 16 && d->K % 16 == 0;
+    const bool whole_tiles = d->K >= 16 && d->K % 16 == 0 && !(d->dyn_count && d->dyn_kind == 2);
     if (whole_tiles && d->M > 64 && d->N > 64 && wgs(128, 128) >= 384) return 1;
     if (d->N > 64 && wgs(64, 128) >= 512) return 2;
     return 3;
@@ -580,6 +596,7 @@ HP_API int hp_gemm_f32(const HpGemmDesc* d, hipStream_t stream) {
     HP_CHECK_ARG(!(d->flags & HP_GEMM_MASK) || d->mask);
     HP_CHECK_ARG(!(d->flags & HP_GEMM_ADD) || d->add);
     HP_CHECK_ARG(!(d->flags & HP_GEMM_ROWSUM) || d->rsum);
+    HP_CHECK_ARG(!d->dyn_count || ((d->dyn_kind == 1 && d->ksplit <= 1 && !(d->flags & HP_GEMM_COLMAX)) || d->dyn_kind == 2));
     HP_CHECK_ARG(d->batch * (long)(d->ksplit > 1 ? d->ksplit : 1) <= 65535);
     KParams p;
     p.A = d->A; p.B = d->B; p.C = d->C; p.bias = d->bias; p.mask = d->mask; p.add = d->add; p.ws = d->ws;
@@ -587,6 +604,7 @@ HP_API int hp_gemm_f32(const HpGemmDesc* d, hipStream_t stream) {
     p.ldadd = d->ldadd;
     p.cmax = d->cmax; p.cidx = d->cidx; p.group_rows = d->group_rows;
     p.rsum = d->rsum; p.sRsumz = d->sRsumz;
+    p.dyn = d->dyn_count; p.dyn_kind = d->dyn_kind;
     p.ws_rsum_off = (long)d->batch * (d->ksplit > 1 ? d->ksplit : 1) * d->M * d->N;
     p.sAi = d->sAi; p.sAk = d->sAk; p.sBk = d->sBk; p.sBj = d->sBj;
     p.ldc = d->ldc; p.ldmask = d->ldmask; p.M = d->M; p.N = d->N; p.K = d->K; p.flags = d->flags;

@@ -30,4 +30,9 @@ typedef struct HpGemmDesc {
     /* HP_GEMM_ROWSUM: rsum(i) at rsum + z*sRsumz + i ; with split-K the workspace needs batch*ksplit*M more floats */
     float* rsum;
     long sRsumz;
+    /* A size known only on the device: dyn_count (device pointer to one int, or NULL) bounds M (dyn_kind 1: rows of
+     * A/C beyond it are neither read nor written) or K (dyn_kind 2: the contraction stops there; split-K ranges
+     * partition the real K).  M / K of this descriptor stay the static upper bounds the launch is sized for. */
+    const int* dyn_count;
+    int dyn_kind;
 } HpGemmDesc;

@@ -304,10 +304,12 @@ class _GemmDesc(ctypes.Structure):
                 ("sAi", c_long), ("sAk", c_long), ("sBk", c_long), ("sBj", c_long),
                 ("ldc", c_int), ("ldmask", c_int), ("ldadd", c_int),
                 ("M", c_int), ("N", c_int), ("K", c_int), ("batch", c_int), ("ksplit", c_int), ("flags", c_int),
-                ("cmax", c_void_p), ("cidx", c_void_p), ("group_rows", c_int), ("rsum", c_void_p), ("sRsumz", c_long)]
+                ("cmax", c_void_p), ("cidx", c_void_p), ("group_rows", c_int), ("rsum", c_void_p), ("sRsumz", c_long),
+                ("dyn_count", c_void_p), ("dyn_kind", c_int)]
 
 
-def gemm(A, B, bias=None, relu=False, trans_a=False, trans_b=True, mask=None, add=None, ksplit=1, rowsum=False, out=None):
+def gemm(A, B, bias=None, relu=False, trans_a=False, trans_b=True, mask=None, add=None, ksplit=1, rowsum=False, out=None,
+         dyn_rows=None, dyn_k=None):
     """Thin test hook over hp_gemm_f32 for 2-D / 3-D (batched) fp32 tensors:
     C = epi(op(A) @ op(B)); trans_b=True means B is stored (N, K) like an nn.Linear weight."""
     batched = A.dim() == 3
@@ -356,6 +358,10 @@ def gemm(A, B, bias=None, relu=False, trans_a=False, trans_b=True, mask=None, ad
         d.rsum, d.sRsumz = rs.data_ptr(), M
         flags |= 32
     d.flags = flags
+    if dyn_rows is not None:      # int32 device tensor with one element: the real number of rows of A / C
+        d.dyn_count, d.dyn_kind = dyn_rows.data_ptr(), 1
+    if dyn_k is not None:         # ... the real contraction length
+        d.dyn_count, d.dyn_kind = dyn_k.data_ptr(), 2
     ws = None
     if ksplit > 1:
         ws = torch.empty((batch * ksplit * (M * N + M),), dtype=torch.float32, device=A.device)

@@ -102,6 +102,33 @@ def test_gemm_epilogues_and_splitk_and_batch():
     grad_close(db, dYb.double().sum(1), tol=1e-5)
 
 
+def test_gemm_device_side_sizes():
+    """HpGemmDesc::dyn_count: the real M (rows) or K (contraction length) lives on the device; the launch is sized for the
+    static bound.  Rows past the count are neither read nor written; a split contraction re-partitions the real K."""
+    from hyperpocket_amd.ops import gemm
+    g = torch.Generator().manual_seed(9)
+    for M, N, K, cnt in [(1024, 256, 128, 333), (4096, 512, 256, 2049), (300, 64, 64, 1), (512, 256, 512, 512)]:
+        A, B = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+        mask = torch.randn(M, N, generator=g)
+        out = torch.full((M, N), 7.0, device="cuda")
+        n = torch.tensor([cnt], dtype=torch.int32, device="cuda")
+        A_d = A.cuda()
+        A_d[cnt:] = float("nan")                                   # must not be read
+        gemm(A_d, B.cuda(), mask=mask.cuda(), dyn_rows=n, out=out)
+        want = (A[:cnt].double() @ B.double().t()) * (mask[:cnt] > 0)
+        grad_close(out[:cnt], want, tol=2e-6 * K ** 0.5)
+        assert torch.all(out[cnt:] == 7.0)
+    for Rmax, C1, C2, cnt, ks in [(4096, 128, 64, 1000, 8), (32768, 512, 256, 11213, 16), (2048, 64, 3, 77, 64), (1024, 64, 64, 1024, 4)]:
+        dY, X = torch.randn(Rmax, C1, generator=g), torch.randn(Rmax, C2, generator=g)
+        n = torch.tensor([cnt], dtype=torch.int32, device="cuda")
+        dY_d, X_d = dY.cuda(), X.cuda()
+        dY_d[cnt:] = float("nan")
+        X_d[cnt:] = float("nan")
+        dW, db = gemm(dY_d, X_d, trans_a=True, trans_b=False, ksplit=ks, rowsum=True, dyn_k=n)
+        grad_close(dW, dY[:cnt].double().t() @ X[:cnt].double(), tol=2e-6 * cnt ** 0.5)
+        grad_close(db, dY[:cnt].double().sum(0), tol=2e-6 * cnt ** 0.5)
+
+
 # ----------------------------------------------------------------------------- components vs oracle
 def test_encoder_forward_backward_vs_oracle(ref):
     from hyperpocket_amd.model.encoder import Encoder
