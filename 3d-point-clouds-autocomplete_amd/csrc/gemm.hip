@@ -114,7 +114,8 @@ __global__ __launch_bounds__(WGM* WGN * 64, (BM >= 128 && BN >= 128) ? ((BM / WG
     // XCD-aware bijective remap of the tile id (cdna_hip_programming.md T1)
     const int nwg = gridDim.x;
     int bid = blockIdx.x;
-    {
+    if (!(p.dyn && p.dyn_kind == 1)) {   // (with a device-side row count the live tiles are the first ones: a contiguous
+                                         //  run per XCD would leave most XCDs idle — keep the round-robin order there)
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
@@ -559,12 +560,15 @@ inline bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 
 constexpr int kCfgRows[4] = {128, 128, 64, 64};
 int choose_cfg(const HpGemmDesc* d, int ksplit) {
     const long zs = (long)d->batch * ksplit;
-    auto wgs = [&](int bm, int bn) { return (long)((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn) * zs; };
+    // a device-side row count is expected to be about a third of its static bound (distinct critical points of an
+    // encoder: ~170 of 512 per cloud): tiles are chosen for that many rows, the grid still covers the bound
+    const int Meff = (d->dyn_count && d->dyn_kind == 1) ? std::max(64, d->M / 3) : d->M;
+    auto wgs = [&](int bm, int bn) { return (long)((Meff + bm - 1) / bm) * ((d->N + bn - 1) / bn) * zs; };
     if (d->N <= 32) return 0;
     // the 128x128 kernel has no K-tail path: whole 16-deep k-tiles per split only
     // (split ranges start at multiples of 32, so K % 16 == 0 makes every range a whole number of k-tiles)
     const bool whole_tiles = d->K >= 16 && d->K % 16 == 0 && !(d->dyn_count && d->dyn_kind == 2);
-    if (whole_tiles && d->M > 64 && d->N > 64 && wgs(128, 128) >= 384) return 1;
+    if (whole_tiles && Meff > 64 && d->N > 64 && wgs(128, 128) >= 384) return 1;
     if (d->N > 64 && wgs(64, 128) >= 512) return 2;
     return 3;
 }

@@ -55,6 +55,7 @@ int pick_ksplit(int outM, int outN, int kc, int batch) {
 struct Op {
     hipStream_t s;
     float* splitws;
+    const int* dyn = nullptr;   // device-side row count of the activation matrices (compacted critical rows), or NULL
     // Y(MxN, ldy) = act(X(MxK, ldx) W(NxK)^T + b)        [batched: strides in floats, 0 = shared]
     int lin_fwd(const float* X, long sXz, int ldx, const float* W, long sWz, const float* b, long sbz, float* Y, long sYz,
                 int ldy, int M, int N, int K, int batch, bool relu) const {
@@ -68,6 +69,11 @@ struct Op {
         if (splitws) {
             d.ksplit = pick_ksplit(M, N, K, batch);
             d.ws = splitws;
+        }
+        if (dyn) {
+            d.dyn_count = dyn;
+            d.dyn_kind = 1;
+            d.ksplit = 1;
         }
         return hp_gemm_f32(&d, s);
     }
@@ -84,6 +90,11 @@ struct Op {
         d.flags = (mask ? HP_GEMM_MASK : 0) | (add ? HP_GEMM_ADD : 0);
         d.ksplit = pick_ksplit(M, K, N, batch);
         d.ws = splitws;
+        if (dyn) {
+            d.dyn_count = dyn;
+            d.dyn_kind = 1;
+            d.ksplit = 1;
+        }
         return hp_gemm_f32(&d, s);
     }
     // dW(NxK) = dY(MxN, ldy)^T X(MxK, ldx)     (contraction over the M rows);  db(N) = column sums of dY ride along
@@ -101,6 +112,10 @@ struct Op {
             d.rsum = db;
             d.sRsumz = sdbz;
             while (d.ksplit > 1 && (long)batch * d.ksplit * ((long)N * K + N) > kSplitWs) --d.ksplit;
+        }
+        if (dyn) {
+            d.dyn_count = dyn;
+            d.dyn_kind = 2;
         }
         return hp_gemm_f32(&d, s);
     }
@@ -208,6 +223,138 @@ __global__ __launch_bounds__(256) void gather_critical_kernel(int Np, const int*
     }
 }
 
+// ---- critical-row compaction -------------------------------------------------------------------------------------
+// Of a cloud's 512 arg-max rows only ~170 are distinct points (tools/crit_unique.py): channels that peak at the same
+// point share every activation below the max-pool, and their gradients simply add.  The backward therefore runs on the
+// DISTINCT critical points: per cloud the channels are sorted by point (bitonic sort in LDS, 512 keys), each distinct
+// point gets a slot, the clouds' slots are packed back to back (`off`), and layers 4..1 see `total` rows — a count that
+// exists only on the device (HpGemmDesc::dyn_count).
+struct Crit {
+    int* chan;     // (B, 512) channels sorted by (point, channel)
+    int* start;    // (B, 513) start[u] = first sorted position of slot u, start[U] = 512
+    int* pt;       // (B, 512) point of slot u
+    int* slot;     // (B, 512) slot of channel c
+    int* cnt;      // (B)      U = number of distinct critical points
+    int* off;      // (B)      first compact row of the cloud
+    int* total;    // (1)      sum of cnt
+};
+
+__global__ __launch_bounds__(512) void crit_unique_kernel(const int* __restrict__ arg, Crit c) {
+    __shared__ int key[512];
+    __shared__ int scan[512];
+    const int b = blockIdx.x, t = threadIdx.x;
+    key[t] = (arg[(long)b * 512 + t] << 9) | t;
+    __syncthreads();
+    for (int k = 2; k <= 512; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int o = t ^ j;
+            if (o > t) {
+                const int x = key[t], y = key[o];
+                const bool up = (t & k) == 0;
+                if ((x > y) == up) {
+                    key[t] = y;
+                    key[o] = x;
+                }
+            }
+            __syncthreads();
+        }
+    const int mine = key[t], p = mine >> 9, ch = mine & 511;
+    const int flag = (t == 0 || (key[t - 1] >> 9) != p) ? 1 : 0;
+    scan[t] = flag;
+    __syncthreads();
+    for (int d = 1; d < 512; d <<= 1) {   // inclusive scan
+        const int v = t >= d ? scan[t - d] : 0;
+        __syncthreads();
+        scan[t] += v;
+        __syncthreads();
+    }
+    const int u = scan[t] - 1;
+    c.chan[(long)b * 512 + t] = ch;
+    c.slot[(long)b * 512 + ch] = u;
+    if (flag) {
+        c.pt[(long)b * 512 + u] = p;
+        c.start[(long)b * 513 + u] = t;
+    }
+    if (t == 511) {
+        c.cnt[b] = u + 1;
+        c.start[(long)b * 513 + u + 1] = 512;
+    }
+}
+
+// off = exclusive prefix sum of cnt over the clouds, total = its end (one workgroup; chunked scan)
+__global__ __launch_bounds__(256) void crit_offsets_kernel(int B, Crit c) {
+    __shared__ int part[256];
+    const int t = threadIdx.x, per = (B + 255) / 256, lo = min(B, t * per), hi = min(B, lo + per);
+    int s = 0;
+    for (int b = lo; b < hi; ++b) s += c.cnt[b];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int i = 0; i < 256; ++i) {
+            const int v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        c.total[0] = run;
+    }
+    __syncthreads();
+    int run = part[t];
+    for (int b = lo; b < hi; ++b) {
+        c.off[b] = run;
+        run += c.cnt[b];
+    }
+}
+
+// One workgroup per (cloud, slot): the distinct critical point's x, h1, h2, h3 out of the forward's per-point arrays
+// into compact row off[b] + slot (16-byte accesses).  h1 == NULL: coordinates only (the recompute path).
+__global__ __launch_bounds__(256) void crit_gather_kernel(int Np, Crit c, const float* __restrict__ x, const float* __restrict__ h1,
+                                                          const float* __restrict__ h2, const float* __restrict__ h3,
+                                                          float* __restrict__ xc, float* __restrict__ c1,
+                                                          float* __restrict__ c2, float* __restrict__ c3) {
+    const int b = blockIdx.x >> 9, u = blockIdx.x & 511;
+    if (u >= c.cnt[b]) return;
+    const long t = c.off[b] + u;
+    const long src = (long)b * Np + c.pt[(long)b * 512 + u];
+    const int i = threadIdx.x;
+    if (h1) {
+        if (i < 16) reinterpret_cast<float4*>(c1 + t * 64)[i] = reinterpret_cast<const float4*>(h1 + src * 64)[i];
+        else if (i < 48) reinterpret_cast<float4*>(c2 + t * 128)[i - 16] = reinterpret_cast<const float4*>(h2 + src * 128)[i - 16];
+        else if (i < 112) reinterpret_cast<float4*>(c3 + t * 256)[i - 48] = reinterpret_cast<const float4*>(h3 + src * 256)[i - 48];
+    }
+    if (i >= 240 && i < 243) xc[t * 3 + (i - 240)] = x[src * 3 + (i - 240)];
+}
+
+// delta4 of a distinct critical point = (its h4 > 0) * sum over the channels that peak there of dg[b,c] * W5[c,:], channels
+// in ascending order.  One workgroup (128 lanes x 4 consecutive k) per (cloud, slot).  h4: the forward's full array
+// (rows b*Np + point) when `full`, else the compact recomputed rows.
+__global__ __launch_bounds__(128) void crit_l5_dx_kernel(int Np, Crit c, const float* __restrict__ dg, const float* __restrict__ W5,
+                                                         const float* __restrict__ h4, int full, float* __restrict__ d4) {
+    const int b = blockIdx.x >> 9, u = blockIdx.x & 511;
+    if (u >= c.cnt[b]) return;
+    const long t = c.off[b] + u;
+    const long hrow = full ? (long)b * Np + c.pt[(long)b * 512 + u] : t;
+    const int k = threadIdx.x * 4;
+    const int i0 = c.start[(long)b * 513 + u], i1 = c.start[(long)b * 513 + u + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = i0; i < i1; ++i) {
+        const int ch = c.chan[(long)b * 512 + i];
+        const float g = dg[(long)b * 512 + ch];
+        const float4 w = *reinterpret_cast<const float4*>(W5 + (long)ch * 512 + k);
+        acc.x = __builtin_fmaf(g, w.x, acc.x);
+        acc.y = __builtin_fmaf(g, w.y, acc.y);
+        acc.z = __builtin_fmaf(g, w.z, acc.z);
+        acc.w = __builtin_fmaf(g, w.w, acc.w);
+    }
+    const float4 hv = *reinterpret_cast<const float4*>(h4 + hrow * 512 + k);
+    float4 o;
+    o.x = hv.x > 0.f ? acc.x : 0.f;
+    o.y = hv.y > 0.f ? acc.y : 0.f;
+    o.z = hv.z > 0.f ? acc.z : 0.f;
+    o.w = hv.w > 0.f ? acc.w : 0.f;
+    *reinterpret_cast<float4*>(d4 + t * 512 + k) = o;
+}
+
 // Layer-5 backward on the critical rows (one-hot upstream):
 //   dW5[c,k]       = sum_b dg[b,c] * h4c[(b,c),k]
 //   d4[(b,c),k]    = dg[b,c] * W5[c,k] * (h4c[(b,c),k] > 0)
@@ -216,9 +363,12 @@ __global__ __launch_bounds__(256) void gather_critical_kernel(int Np, const int*
 // clouds b = g, g + 2, ...; the two b-halves are combined through LDS in a fixed order.
 // h4c: the critical rows' h4, row (b,c) at h4c + (b*C + c)*K — or, with arg != NULL, the forward's full h4 with row
 // (b,c) at h4c + (b*Np + arg[b*C + c])*K (no gathered copy of the widest activation is ever made).
+// With slot/off (critical-row compaction) row (b,c) is compact row off[b] + slot[b*C + c]; d4 == NULL: dW5 / db5 only
+// (delta4 of the compacted rows comes from crit_l5_dx_kernel).
 __global__ __launch_bounds__(256) void enc_l5_bwd_kernel(int B, int C, int K, const float* __restrict__ dg,
                                                          const float* __restrict__ W5, const float* __restrict__ h4c,
-                                                         const int* __restrict__ arg, int Np, float* __restrict__ dW5,
+                                                         const int* __restrict__ arg, int Np, const int* __restrict__ slot,
+                                                         const int* __restrict__ off, float* __restrict__ dW5,
                                                          float* __restrict__ d4, float* __restrict__ db5) {
     __shared__ float4 red[128];
     const int c = blockIdx.x;
@@ -235,7 +385,7 @@ __global__ __launch_bounds__(256) void enc_l5_bwd_kernel(int B, int C, int K, co
         for (int b = g; b < B; b += 2) {
             const long row = (long)b * C + c;
             const float gbc = dg[row];
-            const long src = arg ? (long)b * Np + arg[row] : row;
+            const long src = arg ? (long)b * Np + arg[row] : (slot ? (long)off[b] + slot[row] : row);
             const float4 hv = *reinterpret_cast<const float4*>(h4c + src * K + k);
             s.x = __builtin_fmaf(gbc, hv.x, s.x);
             s.y = __builtin_fmaf(gbc, hv.y, s.y);
@@ -246,7 +396,7 @@ __global__ __launch_bounds__(256) void enc_l5_bwd_kernel(int B, int C, int K, co
             o.y = hv.y > 0.f ? gbc * w.y : 0.f;
             o.z = hv.z > 0.f ? gbc * w.z : 0.f;
             o.w = hv.w > 0.f ? gbc * w.w : 0.f;
-            *reinterpret_cast<float4*>(d4 + row * K + k) = o;
+            if (d4) *reinterpret_cast<float4*>(d4 + row * K + k) = o;
         }
         if (g == 1) red[q] = s;
         __syncthreads();
@@ -284,7 +434,7 @@ __global__ __launch_bounds__(256) void vae_head_bwd_kernel(long n, const float* 
 long enc_fwd_ws(long B, long Np) { return B * Np * (64 + 128 + 256 + 512 + 512); }
 long enc_bwd_ws(long B, long out) {
     const long Rc = B * 512;
-    return Rc * 4 + Rc * (64 + 128 + 256 + 512) * 2 + B * (2 * out + 4 * 512) + kSplitWs + 64;
+    return Rc * 4 + Rc * (64 + 128 + 256 + 512) * 2 + B * (2 * out + 4 * 512) + kSplitWs + 64 + (B * (4 * 512 + 4) + 16);
 }
 
 }  // namespace
@@ -353,6 +503,7 @@ struct EncBwdWs {
     float* hc[5];
     float* dl[5];
     float *dmu, *dlv, *tmp, *dfc, *dg, *split;
+    Crit crit;
 };
 EncBwdWs enc_bwd_layout(float* ws, long B, long out_size) {
     const long Rc = B * 512;
@@ -368,6 +519,14 @@ EncBwdWs enc_bwd_layout(float* ws, long B, long out_size) {
     L.dfc = take(B * 512);
     L.dg = take(B * 512);
     L.split = take(kSplitWs);
+    int* ip = reinterpret_cast<int*>(take(B * (4 * 512 + 4) + 16));
+    L.crit.chan = ip;
+    L.crit.start = L.crit.chan + B * 512;
+    L.crit.pt = L.crit.start + B * 513;
+    L.crit.slot = L.crit.pt + B * 512;
+    L.crit.cnt = L.crit.slot + B * 512;
+    L.crit.off = L.crit.cnt + B;
+    L.crit.total = L.crit.off + B;
     return L;
 }
 }  // namespace
@@ -377,9 +536,30 @@ EncBwdWs enc_bwd_layout(float* ws, long B, long out_size) {
 // one pass over 3.8 KB per critical row; without it (fwd_ws == NULL: the caller dropped the 15 KB/point forward
 // workspace) they are recomputed from the gathered coordinates, the same GEMM chain on B*512 rows.
 static int enc_critical_rows(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size, const int* argidx,
-                             const float* fwd_ws, float* ws, hipStream_t stream) {
+                             const float* fwd_ws, float* ws, int dedup, hipStream_t stream) {
     const long Rc = (long)B * 512;
     EncBwdWs L = enc_bwd_layout(ws, B, out_size);
+    if (dedup) {
+        // distinct critical points only, packed back to back; their number stays on the device (L.crit.total)
+        hipLaunchKernelGGL(crit_unique_kernel, dim3(B), dim3(512), 0, stream, argidx, L.crit);
+        hipLaunchKernelGGL(crit_offsets_kernel, dim3(1), dim3(256), 0, stream, B, L.crit);
+        const long R = (long)B * Np;
+        const float* h1 = fwd_ws;
+        const float* h2 = fwd_ws ? h1 + R * 64 : nullptr;
+        const float* h3 = fwd_ws ? h2 + R * 128 : nullptr;
+        hipLaunchKernelGGL(crit_gather_kernel, dim3((unsigned)Rc), dim3(256), 0, stream, Np, L.crit, x, h1, h2, h3, L.xc, L.hc[1],
+                           L.hc[2], L.hc[3]);
+        if (!fwd_ws) {
+            Op op{stream, nullptr, L.crit.total};
+            const float* in = L.xc;
+            for (int l = 1; l <= 4; ++l) {
+                TRY(op.lin_fwd(in, 0, kEnc[l - 1], w->conv_w[l - 1], 0, w->conv_b[l - 1], 0, L.hc[l], 0, kEnc[l], (int)Rc, kEnc[l],
+                               kEnc[l - 1], 1, true));
+                in = L.hc[l];
+            }
+        }
+        HP_RETURN_LAST_ERROR();
+    }
     if (fwd_ws) {
         const long R = (long)B * Np;
         const float* h1 = fwd_ws;
@@ -404,10 +584,12 @@ static int enc_critical_rows(int B, int Np, const float* x, const HpEncoderWeigh
 // Gradients of every encoder parameter.  grad_out: d/d z (VAE) or d/d mu (plain); grad_mu / grad_explv:
 // direct gradients on the VAE's mu / exp(logvar) outputs (KLD term), may be NULL.  fwd_ws: the workspace
 // hp_encoder_forward ran in, untouched since (NULL: recompute the critical rows' activations instead).
+// dedup != 0: channels that peak at the same point share one row below the max-pool (their gradients add): layers 4..1
+// run on the DISTINCT critical points (~1/3 of B*512), a count that stays on the device.
 HP_API int hp_encoder_backward(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size, int is_vae,
                                const float* eps, const int* argidx, const float* g, const float* f, const float* lv,
                                const float* grad_out, const float* grad_mu, const float* grad_explv,
-                               const HpEncoderGrads* gr, float* ws, const float* fwd_ws, hipStream_t stream) {
+                               const HpEncoderGrads* gr, float* ws, const float* fwd_ws, int dedup, hipStream_t stream) {
     HP_CHECK_ARG(B > 0 && Np > 0 && out_size > 0 && x && w && argidx && g && f && gr && ws);
     HP_CHECK_ARG(grad_out || grad_mu || grad_explv);
     HP_CHECK_ARG(!is_vae || (eps && lv));
@@ -418,7 +600,8 @@ HP_API int hp_encoder_backward(int B, int Np, const float* x, const HpEncoderWei
     float** dl = L.dl;
     float *dmu = L.dmu, *dlv = L.dlv, *tmp = L.tmp, *dfc = L.dfc, *dg = L.dg;
     Op op{stream, L.split};
-    TRY(enc_critical_rows(B, Np, x, w, out_size, argidx, fwd_ws, ws, stream));
+    HP_CHECK_ARG(!dedup || (long)Np * 512 < (1L << 31));
+    TRY(enc_critical_rows(B, Np, x, w, out_size, argidx, fwd_ws, ws, dedup, stream));
 
     // ---- heads (model/encoder.py:46-53)
     const float* dmu_p;
@@ -437,18 +620,28 @@ HP_API int hp_encoder_backward(int B, int Np, const float* x, const HpEncoderWei
     TRY(op.lin_dw(dfc, 0, 512, g, 0, 512, gr->fc_w, 0, B, 512, 512, 1, gr->fc_b));
     TRY(op.lin_dx(dfc, 0, 512, w->fc_w, 0, dg, 0, 512, B, 512, 512, 1, nullptr, 0, 0, nullptr, 0));
 
-    // ---- conv stack on the B*512 critical rows
+    // ---- conv stack on the critical rows (B*512 of them, or the distinct ones)
     const float* h4_full = fwd_ws ? fwd_ws + (long)B * Np * (64 + 128 + 256) : nullptr;
-    hipLaunchKernelGGL(enc_l5_bwd_kernel, dim3(512), dim3(256), 0, stream, B, 512, 512, dg, w->conv_w[4],
-                       h4_full ? h4_full : hc[4], h4_full ? argidx : (const int*)nullptr, Np, gr->conv_w[4],
-                       dl[4], gr->conv_b[4]);
+    Op opc{stream, L.split, dedup ? L.crit.total : nullptr};
+    if (dedup) {
+        hipLaunchKernelGGL(enc_l5_bwd_kernel, dim3(512), dim3(256), 0, stream, B, 512, 512, dg, w->conv_w[4],
+                           h4_full ? h4_full : hc[4], h4_full ? argidx : (const int*)nullptr, Np,
+                           h4_full ? (const int*)nullptr : L.crit.slot, h4_full ? (const int*)nullptr : L.crit.off,
+                           gr->conv_w[4], (float*)nullptr, gr->conv_b[4]);
+        hipLaunchKernelGGL(crit_l5_dx_kernel, dim3((unsigned)Rc), dim3(128), 0, stream, Np, L.crit, dg, w->conv_w[4],
+                           h4_full ? h4_full : hc[4], h4_full ? 1 : 0, dl[4]);
+    } else {
+        hipLaunchKernelGGL(enc_l5_bwd_kernel, dim3(512), dim3(256), 0, stream, B, 512, 512, dg, w->conv_w[4],
+                           h4_full ? h4_full : hc[4], h4_full ? argidx : (const int*)nullptr, Np, (const int*)nullptr,
+                           (const int*)nullptr, gr->conv_w[4], dl[4], gr->conv_b[4]);
+    }
     for (int l = 4; l >= 1; --l) {
         const float* below = l > 1 ? hc[l - 1] : xc;
-        TRY(op.lin_dw(dl[l], 0, kEnc[l], below, 0, kEnc[l - 1], gr->conv_w[l - 1], 0, (int)Rc, kEnc[l], kEnc[l - 1], 1,
-                      gr->conv_b[l - 1]));
+        TRY(opc.lin_dw(dl[l], 0, kEnc[l], below, 0, kEnc[l - 1], gr->conv_w[l - 1], 0, (int)Rc, kEnc[l], kEnc[l - 1], 1,
+                       gr->conv_b[l - 1]));
         if (l > 1)
-            TRY(op.lin_dx(dl[l], 0, kEnc[l], w->conv_w[l - 1], 0, dl[l - 1], 0, kEnc[l - 1], (int)Rc, kEnc[l], kEnc[l - 1], 1,
-                          hc[l - 1], 0, kEnc[l - 1], nullptr, 0));
+            TRY(opc.lin_dx(dl[l], 0, kEnc[l], w->conv_w[l - 1], 0, dl[l - 1], 0, kEnc[l - 1], (int)Rc, kEnc[l], kEnc[l - 1], 1,
+                           hc[l - 1], 0, kEnc[l - 1], nullptr, 0));
     }
     HP_RETURN_LAST_ERROR();
 }

@@ -68,6 +68,9 @@ def _grad_buffer(param):
 # The encoder backward copies the critical rows' activations out of the forward's workspace (15 KB per point, kept
 # alive by the autograd node).  False: drop the workspace after the forward and recompute those rows instead.
 KEEP_ENCODER_ACTIVATIONS = True
+# Channels whose max-pool peaks at the same point share every activation below it: the encoder backward runs its
+# layers 4..1 on the distinct critical points (~170 of 512 per cloud).  False: one row per (cloud, channel).
+DEDUP_CRITICAL_ROWS = True
 
 
 def _encoder_struct(params, cls=_EncoderPtrs):
@@ -129,7 +132,7 @@ class EncoderFunction(Function):
                          device=dev)
         w, gr = _encoder_struct(params), _encoder_struct(out)
         call("hp_encoder_backward", B, Np, x, ctypes.byref(w), ctx.out_size, int(ctx.is_vae), eps, argidx, g, f, lv,
-             gout, gmu, gexplv, ctypes.byref(gr), ws, ctx.fwd_ws, current_stream(dev))
+             gout, gmu, gexplv, ctypes.byref(gr), ws, ctx.fwd_ws, int(DEDUP_CRITICAL_ROWS), current_stream(dev))
         ctx.fwd_ws = None
         return (None, None, None, *out)
 

@@ -183,12 +183,14 @@ int hp_encoder_forward(int B, int Np, const float* x, const HpEncoderWeights* w,
 /* Gradients of every encoder parameter (autograd of the above).  grad_out = d/dz (VAE) or d/dmu (plain);
  * grad_mu / grad_explv = direct gradients on the VAE outputs (may be NULL).  Only the 512 arg-max points of a
  * cloud carry gradient below the max-pool: their activations are copied out of fwd_ws (the workspace
- * hp_encoder_forward ran in, untouched since) or, with fwd_ws = NULL, recomputed from x. */
+ * hp_encoder_forward ran in, untouched since) or, with fwd_ws = NULL, recomputed from x.  dedup != 0: channels that
+ * peak at the same point share one row (their gradients add), so the layers below run on the DISTINCT critical
+ * points, about a third of B*512; same gradients up to fp32 summation order. */
 long hp_encoder_backward_workspace_floats(int B, int out_size);
 int hp_encoder_backward(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size, int is_vae,
                         const float* eps, const int* argidx, const float* g, const float* f, const float* lv,
                         const float* grad_out, const float* grad_mu, const float* grad_explv, const HpEncoderGrads* grads,
-                        float* ws, const float* fwd_ws, hpStream_t stream);
+                        float* ws, const float* fwd_ws, int dedup, hpStream_t stream);
 
 /* HyperNetwork.forward (model/hyper_network.py:41-43): latent (B,in) -> theta (B,theta_ld); t = saved trunk
  * activations (hp_hypernet_saved_floats floats) for the backward. */

@@ -195,6 +195,36 @@ def test_encoder_backward_gather_equals_recompute():
             assert torch.equal(grads[0][k], grads[1][k]), k
 
 
+def test_encoder_backward_distinct_critical_points_equal_per_channel_rows():
+    """Merging the channels that peak at the same point (ops.DEDUP_CRITICAL_ROWS: layers 4..1 on the distinct critical
+    points, a device-side row count) gives the per-channel-row gradients up to fp32 summation order — including clouds
+    where every channel peaks at ONE point and clouds where (nearly) all 512 differ."""
+    from hyperpocket_amd import ops
+    from hyperpocket_amd.model.encoder import Encoder
+    from hyperpocket_amd.core.setup import weights_init
+    for is_vae, B, Np in [(True, 5, 1024), (False, 3, 300), (True, 2, 1), (False, 2, 4000)]:
+        torch.manual_seed(13 + Np)
+        enc = Encoder({"output_size": 128, "use_bias": True, "relu_slope": 0.2}, is_vae=is_vae).apply(weights_init).cuda()
+        x = (torch.rand(B, Np, 3, device="cuda") - 0.5).transpose(1, 2)
+        eps = torch.randn(B, 128, device="cuda")
+        grads = []
+        for dedup in (True, False):
+            for keep in (True, False):
+                ops.DEDUP_CRITICAL_ROWS, ops.KEEP_ENCODER_ACTIVATIONS = dedup, keep
+                try:
+                    for p in enc.parameters():
+                        p.grad = None
+                    out = enc(x, eps) if is_vae else (enc(x),)
+                    sum((o * (i + 1.5)).sum() for i, o in enumerate(out)).backward()
+                finally:
+                    ops.DEDUP_CRITICAL_ROWS, ops.KEEP_ENCODER_ACTIVATIONS = True, True
+                grads.append({k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None})
+        for k in grads[0]:
+            assert torch.equal(grads[0][k], grads[1][k]), k          # dedup: gather == recompute, bit for bit
+            assert torch.equal(grads[2][k], grads[3][k]), k          # per-channel rows: likewise
+            grad_close(grads[0][k], grads[2][k], tol=2e-5)
+
+
 def test_hypernet_forward_backward_vs_oracle(ref):
     from hyperpocket_amd.model.hyper_network import HyperNetwork
     from hyperpocket_amd.core.setup import weights_init

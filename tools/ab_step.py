@@ -14,10 +14,17 @@ def run(n):
     eng.finish_pending(); torch.cuda.synchronize()
 def t(n=40):
     run(5); t0 = time.perf_counter(); run(n); return (time.perf_counter() - t0) / n * 1e3
+from hyperpocket_amd import ops
+flags = [a.split("=") for a in sys.argv[1:]]          # e.g. DEDUP_CRITICAL_ROWS=0  -> also run with that ops flag flipped
 for rep in range(3):
     for emd in (0.05, 0.0):
         eng.emd_coef = emd
         print(f"emd={emd}: {t():.4f} ms", flush=True)
+        for name, val in flags:
+            old = getattr(ops, name)
+            setattr(ops, name, type(old)(int(val)))
+            print(f"emd={emd} {name}={val}: {t():.4f} ms", flush=True)
+            setattr(ops, name, old)
 # CPU enqueue time
 eng.emd_coef = 0.05
 run(5); torch.cuda.synchronize(); t0 = time.perf_counter()
