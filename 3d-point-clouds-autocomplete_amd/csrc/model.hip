@@ -360,19 +360,19 @@ __global__ __launch_bounds__(128) void crit_l5_dx_kernel(int Np, Crit c, const f
 //   d4[(b,c),k]    = dg[b,c] * W5[c,k] * (h4c[(b,c),k] > 0)
 //   db5[c]         = sum_b dg[b,c]
 // One workgroup per channel c; K % 4 == 0.  Thread (q = tid & 127, g = tid >> 7) owns 4 consecutive k and the
-// clouds b = g, g + 2, ...; the two b-halves are combined through LDS in a fixed order.
+// clouds b = g, g + 4, ...; the four cloud groups are combined through LDS in a fixed order.
 // h4c: the critical rows' h4, row (b,c) at h4c + (b*C + c)*K — or, with arg != NULL, the forward's full h4 with row
 // (b,c) at h4c + (b*Np + arg[b*C + c])*K (no gathered copy of the widest activation is ever made).
 // With slot/off (critical-row compaction) row (b,c) is compact row off[b] + slot[b*C + c]; d4 == NULL: dW5 / db5 only
 // (delta4 of the compacted rows comes from crit_l5_dx_kernel).
-__global__ __launch_bounds__(256) void enc_l5_bwd_kernel(int B, int C, int K, const float* __restrict__ dg,
+__global__ __launch_bounds__(512) void enc_l5_bwd_kernel(int B, int C, int K, const float* __restrict__ dg,
                                                          const float* __restrict__ W5, const float* __restrict__ h4c,
                                                          const int* __restrict__ arg, int Np, const int* __restrict__ slot,
                                                          const int* __restrict__ off, float* __restrict__ dW5,
                                                          float* __restrict__ d4, float* __restrict__ db5) {
-    __shared__ float4 red[128];
+    __shared__ float4 red[3][128];
     const int c = blockIdx.x;
-    const int q = threadIdx.x & 127, g = threadIdx.x >> 7;
+    const int q = threadIdx.x & 127, g = threadIdx.x >> 7;   // g = 0..3: clouds b = g, g + 4, ...
     if (threadIdx.x == 0) {
         float s = 0.f;
         for (int b = 0; b < B; ++b) s += dg[(long)b * C + c];
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void enc_l5_bwd_kernel(int B, int C, int K, co
         const float4 w = *reinterpret_cast<const float4*>(W5 + (long)c * K + k);
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
-        for (int b = g; b < B; b += 2) {
+        for (int b = g; b < B; b += 4) {
             const long row = (long)b * C + c;
             const float gbc = dg[row];
             const long src = arg ? (long)b * Np + arg[row] : (slot ? (long)off[b] + slot[row] : row);
@@ -391,18 +391,22 @@ __global__ __launch_bounds__(256) void enc_l5_bwd_kernel(int B, int C, int K, co
             s.y = __builtin_fmaf(gbc, hv.y, s.y);
             s.z = __builtin_fmaf(gbc, hv.z, s.z);
             s.w = __builtin_fmaf(gbc, hv.w, s.w);
-            float4 o;
-            o.x = hv.x > 0.f ? gbc * w.x : 0.f;
-            o.y = hv.y > 0.f ? gbc * w.y : 0.f;
-            o.z = hv.z > 0.f ? gbc * w.z : 0.f;
-            o.w = hv.w > 0.f ? gbc * w.w : 0.f;
-            if (d4) *reinterpret_cast<float4*>(d4 + row * K + k) = o;
+            if (d4) {
+                float4 o;
+                o.x = hv.x > 0.f ? gbc * w.x : 0.f;
+                o.y = hv.y > 0.f ? gbc * w.y : 0.f;
+                o.z = hv.z > 0.f ? gbc * w.z : 0.f;
+                o.w = hv.w > 0.f ? gbc * w.w : 0.f;
+                *reinterpret_cast<float4*>(d4 + row * K + k) = o;
+            }
         }
-        if (g == 1) red[q] = s;
+        if (g) red[g - 1][q] = s;
         __syncthreads();
-        if (g == 0) {
-            const float4 t = red[q];
-            *reinterpret_cast<float4*>(dW5 + (long)c * K + k) = make_float4(s.x + t.x, s.y + t.y, s.z + t.z, s.w + t.w);
+        if (g == 0) {   // the four cloud groups in a fixed order
+            const float4 t1 = red[0][q], t2 = red[1][q], t3 = red[2][q];
+            *reinterpret_cast<float4*>(dW5 + (long)c * K + k) =
+                make_float4(((s.x + t1.x) + t2.x) + t3.x, ((s.y + t1.y) + t2.y) + t3.y, ((s.z + t1.z) + t2.z) + t3.z,
+                            ((s.w + t1.w) + t2.w) + t3.w);
         }
         __syncthreads();
     }
@@ -624,14 +628,14 @@ HP_API int hp_encoder_backward(int B, int Np, const float* x, const HpEncoderWei
     const float* h4_full = fwd_ws ? fwd_ws + (long)B * Np * (64 + 128 + 256) : nullptr;
     Op opc{stream, L.split, dedup ? L.crit.total : nullptr};
     if (dedup) {
-        hipLaunchKernelGGL(enc_l5_bwd_kernel, dim3(512), dim3(256), 0, stream, B, 512, 512, dg, w->conv_w[4],
+        hipLaunchKernelGGL(enc_l5_bwd_kernel, dim3(512), dim3(512), 0, stream, B, 512, 512, dg, w->conv_w[4],
                            h4_full ? h4_full : hc[4], h4_full ? argidx : (const int*)nullptr, Np,
                            h4_full ? (const int*)nullptr : L.crit.slot, h4_full ? (const int*)nullptr : L.crit.off,
                            gr->conv_w[4], (float*)nullptr, gr->conv_b[4]);
         hipLaunchKernelGGL(crit_l5_dx_kernel, dim3((unsigned)Rc), dim3(128), 0, stream, Np, L.crit, dg, w->conv_w[4],
                            h4_full ? h4_full : hc[4], h4_full ? 1 : 0, dl[4]);
     } else {
-        hipLaunchKernelGGL(enc_l5_bwd_kernel, dim3(512), dim3(256), 0, stream, B, 512, 512, dg, w->conv_w[4],
+        hipLaunchKernelGGL(enc_l5_bwd_kernel, dim3(512), dim3(512), 0, stream, B, 512, 512, dg, w->conv_w[4],
                            h4_full ? h4_full : hc[4], h4_full ? argidx : (const int*)nullptr, Np, (const int*)nullptr,
                            (const int*)nullptr, gr->conv_w[4], dl[4], gr->conv_b[4]);
     }
