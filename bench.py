@@ -54,13 +54,14 @@ def synth_batch(b, n_half, device, seed):
 def event_time_ms(fn, iters, warm=2):
     """Average duration of fn() measured with HIP events on the stream fn launches on (torch's current stream).
     The events bracket back-to-back launches, so a host-side pause longer than the queued work would be counted as
-    kernel time: Python's cyclic collector (a 30 ms gen-2 pass was observed here) is held off for the region."""
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
+    kernel time: Python's cyclic collector (a 30 ms gen-2 pass was observed here) is held off for the region.  The
+    start event is recorded straight behind the warm-up launches, with no synchronisation in between: an idle gap there
+    makes the chip re-ramp its clock inside the timed region (measured: 102 vs 113-118 TFLOP/s on the same launches)."""
     gc.collect()
     gc.disable()
     try:
+        for _ in range(warm):
+            fn()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         for _ in range(iters):
@@ -84,7 +85,7 @@ def roofline_dominant_kernel(batch, n_half):
     w = torch.randn(512, 512, device="cuda") * 0.05
     b = torch.zeros(512, device="cuda")
     c = torch.empty(m, 512, device="cuda")
-    ms = event_time_ms(lambda: gemm(a, w, bias=b, out=c), iters=20, warm=3)
+    ms = event_time_ms(lambda: gemm(a, w, bias=b, out=c), iters=40, warm=20)
     flops = 2.0 * m * 512 * 512
     achieved = flops / (ms * 1e-3) / 1e12
     traffic = None
