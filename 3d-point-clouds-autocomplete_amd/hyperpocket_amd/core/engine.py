@@ -19,20 +19,22 @@ from ..parallel import FlatParameters, GradientReducer
 class TrainEngine:
     _DEFERRED = (1, 0)   # buckets whose exchange + update cross the step boundary when world > 1: trunk, heads
 
-    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, loss_coef=0.05, emd_coef=0.0, process_group=None):
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, loss_coef=0.05, emd_coef=0.0, process_group=None,
+                 force_exchange=False):
         self.model = model
         self.lr, self.betas, self.eps = lr, betas, eps
         self.loss_coef, self.emd_coef = loss_coef, emd_coef
         self.flat = FlatParameters(model)
-        self.reducer = GradientReducer(self.flat, process_group)
+        self.reducer = GradientReducer(self.flat, process_group, force=force_exchange)
         self.world = self.reducer.world
+        self.exchange = self.reducer.active      # world > 1, or a one-rank group asked to run the collectives anyway
         self.exp_avg = torch.zeros_like(self.flat.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat.flat)
         self.steps = 0
         self._heads_pending = False
         model._pre_hypernet_hook = self.finish_pending     # FullModel.forward calls it right before the hypernetwork
         self._consts = {}
-        if self.world > 1:
+        if self.exchange:
             # replicas start from rank 0's weights
             dist.broadcast(self.flat.flat, src=0, group=process_group)
 
@@ -53,7 +55,7 @@ class TrainEngine:
                                 list(gt.shape), epoch, device, points=points, eps=eps_noise)
         rec_n3 = rec.permute(0, 2, 1)
         roots, root_grads, out = self._losses_and_gradients(gt, rec_n3, logvar, mu)
-        if self.world > 1:
+        if self.exchange:
             # the hypernetwork's gradients (90 % of the bytes) are complete once its backward has been
             # enqueued; ship them while the encoders' backward still runs
             self._install_overlap_hook()
@@ -64,7 +66,7 @@ class TrainEngine:
         # NEXT step's hypernetwork forward, which comes after ~1 ms of encoder forward: their all-reduces stay in flight
         # across the step boundary and `finish_pending` (called by FullModel.forward right before the hypernetwork)
         # waits for them and applies their Adam updates there.
-        if self.world == 1:
+        if not self.exchange:
             self._adam_range(0, self.flat.total)     # nothing to exchange: one pass over the whole flat buffer
             self._heads_pending = False
             return out

@@ -134,7 +134,11 @@ def _side_stream(model, device):
     streams = model.__dict__.setdefault("_side_streams", {})
     key = (device.type, device.index)
     if key not in streams:
-        streams[key] = torch.cuda.Stream(device=device)
+        # high priority: ROCclr keeps a separate pool of hardware queues per priority, so this stream can never be
+        # folded onto the hardware queue of the caller's (normal-priority) stream.  It is at GPU_MAX_HW_QUEUES=4 (the
+        # default) once a process group's streams exist: normal-pool streams then share queues, the two encoders
+        # serialise and a step loses 0.45 ms (measured; tools/micro/stream_queues.py shows the mapping).
+        streams[key] = torch.cuda.Stream(device=device, priority=-1)
     return streams[key]
 
 

@@ -23,6 +23,11 @@ import os
 import sys
 import time
 
+# ROCclr multiplexes HIP streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues per priority; streams that share
+# one serialise.  The step uses the caller's stream, a side stream and RCCL's stream(s): give each its own queue.
+# Must be in the environment before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch
 import torch.distributed as dist
 
@@ -157,7 +162,12 @@ def main():
     backend = os.environ.get("HP_BENCH_BACKEND", "nccl")
     if os.environ.get("HP_BENCH_ONE_DEVICE"):
         local_rank = 0
-    if world > 1:
+    # Test hook (not used by the driver): HP_BENCH_FORCE_EXCHANGE=1 at WORLD_SIZE=1 forms a one-rank RCCL group and runs
+    # every collective of the multi-rank step in it (broadcast, bucketed async all-reduce, deferred waits, barrier).
+    force_exchange = bool(os.environ.get("HP_BENCH_FORCE_EXCHANGE")) and world == 1
+    if force_exchange:
+        os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1 or force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
@@ -170,6 +180,7 @@ def main():
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     device = torch.device("cuda", local_rank if world > 1 else 0)
+    grouped = world > 1 or force_exchange
 
     from hyperpocket_amd.core.engine import TrainEngine
     from hyperpocket_amd.core.setup import weights_init
@@ -182,12 +193,13 @@ def main():
     model = model.to(device)
     torch.manual_seed(2020 + rank)              # per-rank streams for eps / decoder points
     emd_coef = 0.0 if args.no_emd else 0.05
-    engine = TrainEngine(model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, loss_coef=0.05, emd_coef=emd_coef)
+    engine = TrainEngine(model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, loss_coef=0.05, emd_coef=emd_coef,
+                         force_exchange=force_exchange)
     ex, mi, gt = synth_batch(args.batch, n_half, device, 2020 + rank)
 
     def sync():
         engine.finish_pending()     # the heads' all-reduce + Adam of the last step (deferred across the step boundary)
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -202,7 +214,7 @@ def main():
     out = run(args.steps)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -244,7 +256,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n_half, emd_coef)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 
