@@ -719,10 +719,19 @@ HP_API int hp_hypernet_backward(int B, int in_size, const float* latent, const H
     // heads: dW_h = dtheta_h^T t5 ; db_h = colsum ; dt5 = sum_h dtheta_h W_h
     int off = 0, total = 0;
     for (int hd = 0; hd < w->n_heads; ++hd) total += w->head_out[hd];
+    // gr->head_w[0] == NULL: the caller forms the heads' weight gradient itself (data-parallel ranks exchange d theta and
+    // t5 and each computes a row slice of the GLOBAL dW: hp_hypernet_heads_dw_rows); only the bias gradients are made here
+    const bool skip_dw = gr->head_w[0] == nullptr;
+    bool gb_contig = true;
+    for (int h = 0; h + 1 < w->n_heads; ++h) gb_contig = gb_contig && gr->head_b[h + 1] == gr->head_b[h] + w->head_out[h];
+    HP_CHECK_ARG(!skip_dw || (gb_contig && heads_contiguous(w->head_w, w->head_b, w->head_out, w->n_heads)));
     const bool fused = heads_contiguous(w->head_w, w->head_b, w->head_out, w->n_heads) &&
-                       heads_contiguous(gr->head_w, gr->head_b, w->head_out, w->n_heads);
+                       (skip_dw || heads_contiguous(gr->head_w, gr->head_b, w->head_out, w->n_heads));
     if (fused) {
-        TRY(op.lin_dw(grad_theta, 0, theta_ld, act[4], 0, 2048, gr->head_w[0], 0, B, total, 2048, 1, gr->head_b[0]));
+        if (!skip_dw)
+            TRY(op.lin_dw(grad_theta, 0, theta_ld, act[4], 0, 2048, gr->head_w[0], 0, B, total, 2048, 1, gr->head_b[0]));
+        else if (gr->head_b[0])
+            TRY(op.colsum(grad_theta, 0, theta_ld, B, total, 1, gr->head_b[0], 0));
         TRY(op.lin_dx(grad_theta, 0, theta_ld, w->head_w[0], 0, dt[4], 0, 2048, B, total, 2048, 1, nullptr, 0, 0, nullptr, 2048));
     }
     for (int hd = 0; hd < w->n_heads && !fused; ++hd) {
@@ -744,6 +753,24 @@ HP_API int hp_hypernet_backward(int B, int in_size, const float* latent, const H
             TRY(op.lin_dx(dt[0], 0, kTrunk[0], w->trunk_w[0], 0, grad_latent, 0, kin, B, kTrunk[0], kin, 1, nullptr, 0, 0,
                           nullptr, 0));
     }
+    HP_RETURN_LAST_ERROR();
+}
+
+// Rows [r0, r0+rows) of the heads' weight gradient from factors gathered over the data-parallel ranks:
+//   dW_rows (rows x 2048) = dtheta_all[:, r0 : r0+rows]^T (rows x Kc) . t5_all (Kc x 2048),   Kc = sum of the ranks' batches.
+// The heads' dW is a rank-B product, so ranks exchange its factors (B x (19011 + 2048) floats each) instead of the
+// 156 MB matrix; rank r forms only its row slice of the global gradient (same flops as its local dW: rows shrink by the
+// world size, the contraction grows by it).  t5_all is a plain (Kc x 2048) matrix: the caller gathers the t5 block of
+// every rank's hp_hypernet_forward `t` (it starts hp_hypernet_t5_offset(B) floats in).  ws: hp_hypernet_heads_dw_workspace_floats() floats.
+HP_API long hp_hypernet_t5_offset(int B) { return (long)B * (64 + 128 + 512 + 1024); }
+HP_API long hp_hypernet_heads_dw_workspace_floats(void) { return kSplitWs + 64; }
+HP_API int hp_hypernet_heads_dw_rows(int Kc, int rows, int r0, const float* dtheta_all, int theta_ld, const float* t5_all,
+                                     float* dW_rows, float* ws, hipStream_t stream) {
+    HP_CHECK_ARG(Kc > 0 && rows >= 0 && r0 >= 0 && r0 + rows <= theta_ld && dtheta_all && t5_all && ws);
+    if (rows == 0) return 0;
+    HP_CHECK_ARG(dW_rows);
+    Op op{stream, ws};
+    TRY(op.lin_dw(dtheta_all + r0, 0, theta_ld, t5_all, 0, 2048, dW_rows, 0, Kc, rows, 2048, 1));
     HP_RETURN_LAST_ERROR();
 }
 

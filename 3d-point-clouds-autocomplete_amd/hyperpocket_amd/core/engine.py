@@ -16,11 +16,90 @@ from .._lib import call, check_input, current_stream, load_library
 from ..parallel import FlatParameters, GradientReducer
 
 
+class HeadsShard:
+    """Sharded update of the hypernetwork heads under data parallelism (ZeRO-1 over the heads' weight matrix, made cheap
+    by the gradient's structure).  The heads are 90 % of the parameters (19011 x 2048 = 156 MB) but their gradient is a
+    rank-B product  dW = d theta^T . t5.  Instead of all-reducing 156 MB per step, ranks all-gather the two factors
+    (B x (19011 + 2048) floats each: 5.4 MB), rank r forms rows [r*R, (r+1)*R) of the GLOBAL gradient (contraction over
+    all world*B clouds: the same flops as its local dW), applies Adam to those rows only (1/world of the heads' Adam
+    traffic) and the updated rows are all-gathered in place (78 MB sent per rank at any world size: half the bytes of
+    the all-reduce, and nothing of it is on the critical path: it is waited for right before the NEXT step's
+    hypernetwork forward).  Every rank must run the same batch size."""
+
+    def __init__(self, flat, reducer, adam_range):
+        h = flat.heads
+        self.flat, self.reducer, self.adam_range = flat, reducer, adam_range
+        self.world, self.rank = reducer.world, reducer.rank
+        self.lo, self.rows, self.cols = h["lo"], h["rows"], h["cols"]
+        self.R = h["pad_rows"] // self.world                      # rows owned per rank (pad rows: zero weights, zero grads)
+        self.r0 = self.rank * self.R
+        self.rows_here = max(0, min(self.R, self.rows - self.r0))
+        self.hi = h["hi"]
+        self._bufs = {}
+        self.pending = False
+        self.step = 0
+        self.weights_in_flight = False
+
+    @staticmethod
+    def usable(flat, world):
+        return flat.heads is not None and flat.heads["pad_rows"] % world == 0 and flat.heads["cols"] == 2048
+
+    def accepts(self, head_weights):
+        base = self.flat.flat.data_ptr() + 4 * self.lo
+        off = 0
+        for p in head_weights:
+            if p.data_ptr() != base + 4 * off:
+                return False
+            off += p.numel()
+        return off == self.rows * self.cols
+
+    def begin(self, grad_theta, t5):
+        B = grad_theta.size(0)
+        if grad_theta.size(1) != self.rows:
+            raise RuntimeError(f"HeadsShard: d theta has {grad_theta.size(1)} columns, the heads have {self.rows} rows")
+        key = (B, grad_theta.device)
+        if key not in self._bufs:
+            f32 = dict(dtype=torch.float32, device=grad_theta.device)
+            lib = load_library()
+            lib.hp_hypernet_heads_dw_workspace_floats.restype = ctypes.c_long
+            self._bufs[key] = (torch.empty((self.world * B, self.rows), **f32), torch.empty((self.world * B, 2048), **f32),
+                               torch.empty((lib.hp_hypernet_heads_dw_workspace_floats(),), **f32))
+        self._cur = self._bufs[key]
+        self._keep = (grad_theta, t5)          # inputs of the in-flight gathers
+        self.reducer.all_gather("dtheta", self._cur[0], grad_theta)
+        self.reducer.all_gather("t5", self._cur[1], t5)
+        self.pending = True
+
+    def update(self):
+        """Own rows of the global dW -> Adam on them -> all-gather of the updated rows (asynchronous)."""
+        if not self.pending:
+            return
+        self.reducer.wait("dtheta")
+        self.reducer.wait("t5")
+        dth, t5, ws = self._cur
+        flat = self.flat
+        lo = self.lo + self.r0 * self.cols
+        hi = lo + self.R * self.cols
+        if self.rows_here:
+            call("hp_hypernet_heads_dw_rows", dth.size(0), self.rows_here, self.r0, dth, dth.size(1), t5,
+                 flat.grad[lo:lo + self.rows_here * self.cols], ws, current_stream(dth.device))
+        self.adam_range(lo, hi)
+        self.reducer.all_gather("heads_w", flat.flat[self.lo:self.hi], flat.flat[lo:hi])
+        self.weights_in_flight = True
+        self.pending = False
+        self._keep = None
+
+    def wait_weights(self):
+        if self.weights_in_flight:
+            self.reducer.wait("heads_w")
+            self.weights_in_flight = False
+
+
 class TrainEngine:
     _DEFERRED = (1, 0)   # buckets whose exchange + update cross the step boundary when world > 1: trunk, heads
 
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, loss_coef=0.05, emd_coef=0.0, process_group=None,
-                 force_exchange=False):
+                 force_exchange=False, shard_heads=True):
         self.model = model
         self.lr, self.betas, self.eps = lr, betas, eps
         self.loss_coef, self.emd_coef = loss_coef, emd_coef
@@ -34,11 +113,23 @@ class TrainEngine:
         self._heads_pending = False
         model._pre_hypernet_hook = self.finish_pending     # FullModel.forward calls it right before the hypernetwork
         self._consts = {}
+        # the heads' update: sharded over the ranks (HeadsShard) when the layout allows it, else all-reduced like the rest
+        self.shard = None
+        if self.exchange and shard_heads and HeadsShard.usable(self.flat, self.world):
+            self.shard = HeadsShard(self.flat, self.reducer, self._adam_range)
         if self.exchange:
             # replicas start from rank 0's weights
             dist.broadcast(self.flat.flat, src=0, group=process_group)
 
     def _after_hypernet_backward(self, *_):
+        if self.shard is not None:
+            # d theta / t5 were gathered under the hypernetwork's own backward launches; the heads' rows are updated
+            # and on their way before the encoders' backward is even enqueued
+            ops.HEADS_DW_EXCHANGE = None
+            self.shard.update()
+            lo, hi = self.shard.hi, self.flat.buckets[1][1]      # heads' biases + trunk: plain all-reduce, deferred
+            self.reducer.launch("small", lo, hi)
+            return
         self.reducer.launch(0)
         self.reducer.launch(1)
 
@@ -55,12 +146,17 @@ class TrainEngine:
                                 list(gt.shape), epoch, device, points=points, eps=eps_noise)
         rec_n3 = rec.permute(0, 2, 1)
         roots, root_grads, out = self._losses_and_gradients(gt, rec_n3, logvar, mu)
+        self.steps += 1
         if self.exchange:
             # the hypernetwork's gradients (90 % of the bytes) are complete once its backward has been
             # enqueued; ship them while the encoders' backward still runs
             self._install_overlap_hook()
-        torch.autograd.backward(roots, root_grads)
-        self.steps += 1
+            if self.shard is not None:
+                ops.HEADS_DW_EXCHANGE = self.shard
+        try:
+            torch.autograd.backward(roots, root_grads)
+        finally:
+            ops.HEADS_DW_EXCHANGE = None
         # Exchange + update per bucket.  The encoders' bucket (6.6 MB) is reduced and updated now: the next step starts
         # with it.  The hypernetwork's buckets (heads 156 MB, trunk 11 MB: 96 % of the bytes) are only needed again in the
         # NEXT step's hypernetwork forward, which comes after ~1 ms of encoder forward: their all-reduces stay in flight
@@ -69,6 +165,13 @@ class TrainEngine:
         if not self.exchange:
             self._adam_range(0, self.flat.total)     # nothing to exchange: one pass over the whole flat buffer
             self._heads_pending = False
+            return out
+        if self.shard is not None:
+            self._after_hypernet_backward()       # no-op when the latent's hook already ran it
+            self.reducer.launch(2)
+            self.reducer.wait(2)
+            self._adam(2)
+            self._heads_pending = True
             return out
         self.reducer.launch_all()
         for b in range(len(self.flat.buckets) - 1, -1, -1):
@@ -166,6 +269,11 @@ class TrainEngine:
 
     def finish_pending(self):
         """Complete the deferred hypernetwork updates (idempotent).  Call before reading the parameters outside `step`."""
+        if self._heads_pending and self.shard is not None:
+            self.reducer.wait("small")
+            self._adam_range(self.shard.hi, self.flat.buckets[1][1])
+            self.shard.wait_weights()
+            self._heads_pending = False
         if self._heads_pending:
             for b in self._DEFERRED:
                 if b < len(self.flat.buckets):

@@ -137,6 +137,12 @@ class EncoderFunction(Function):
         return (None, None, None, *out)
 
 
+# Data parallelism: an object with `accepts(head_weights) -> bool` and `begin(grad_theta, t5)` (core/engine.py
+# HeadsShard).  When set and accepting, the hypernetwork backward leaves the heads' weight gradient to it: the ranks
+# exchange the gradient's two factors (d theta, t5) instead of the 156 MB matrix.
+HEADS_DW_EXCHANGE = None
+
+
 class HyperNetFunction(Function):
     """model/hyper_network.py:41-43.  params: trunk_w x5, trunk_b x5, head_w x H, head_b x H."""
 
@@ -170,7 +176,9 @@ class HyperNetFunction(Function):
         B, in_size = latent.shape
         dev = latent.device
         w, gr = _HyperWeights(), _HyperGrads()
-        out = [_grad_buffer(p) for p in params]
+        exch = HEADS_DW_EXCHANGE
+        external_dw = exch is not None and exch.accepts(params[10:10 + n_heads])
+        out = [None if external_dw and 10 <= i < 10 + n_heads else _grad_buffer(p) for i, p in enumerate(params)]
         for i in range(5):
             w.trunk_w[i], w.trunk_b[i] = _dp(params[i]), _dp(params[5 + i])
             gr.trunk_w[i], gr.trunk_b[i] = _dp(out[i]), _dp(out[5 + i])
@@ -178,6 +186,10 @@ class HyperNetFunction(Function):
         for h in range(n_heads):
             w.head_w[h], w.head_b[h], w.head_out[h] = _dp(params[10 + h]), _dp(params[10 + n_heads + h]), params[10 + h].size(0)
             gr.head_w[h], gr.head_b[h] = _dp(out[10 + h]), _dp(out[10 + n_heads + h])
+        if external_dw:
+            # issued before this rank's backward launches, so the gathers travel under them
+            o5 = _long_fn("hp_hypernet_t5_offset", B)
+            exch.begin(grad_theta, t[o5:o5 + B * 2048].view(B, 2048))
         grad_latent = torch.empty_like(latent) if ctx.needs_input_grad[0] else None
         ws = torch.empty((_long_fn("hp_hypernet_backward_workspace_floats", B),), dtype=torch.float32, device=dev)
         call("hp_hypernet_backward", B, in_size, latent, ctypes.byref(w), t, grad_theta, grad_theta.size(1), ctypes.byref(gr),

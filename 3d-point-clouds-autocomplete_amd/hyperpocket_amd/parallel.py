@@ -17,6 +17,9 @@ import torch.distributed as dist
 from . import ops
 
 
+HEAD_ROW_MULTIPLE = 8
+
+
 def _aligned(n, a=4):
     return (n + a - 1) // a * a
 
@@ -41,12 +44,29 @@ class FlatParameters:
         self.params = [p for _, p in named]
         dev = self.params[0].device
         offs, total, bounds = [], 0, {}
-        for n, p in named:
+        head_w = [(n, p) for n, p in named if bucket_of(n) == 0 and not n.endswith(".bias")]
+        # The heads' weights, back to back, are one (rows x cols) matrix; its row count is padded to a multiple of
+        # HEAD_ROW_MULTIPLE (zero rows nobody reads) so that 1, 2, 4 or 8 ranks can each own an equal row slice of it
+        # (TrainEngine's sharded heads update).  None when the model has no trainable heads / irregular ones.
+        self.heads = None
+        for i, (n, p) in enumerate(named):
             b = bucket_of(n)
             bounds.setdefault(b, [total, total])
             offs.append(total)
             total = _aligned(total + p.numel())
+            if head_w and n == head_w[-1][0]:
+                cols = head_w[0][1].size(1)
+                rows = sum(q.size(0) for _, q in head_w)
+                regular = all(q.dim() == 2 and q.size(1) == cols for _, q in head_w) and cols % 4 == 0 \
+                    and total - bounds[0][0] == rows * cols
+                if regular:
+                    pad_rows = (rows + HEAD_ROW_MULTIPLE - 1) // HEAD_ROW_MULTIPLE * HEAD_ROW_MULTIPLE
+                    self.heads = {"lo": bounds[0][0], "rows": rows, "pad_rows": pad_rows, "cols": cols}
+                    total = bounds[0][0] + pad_rows * cols
             bounds[b][1] = total
+        if self.heads is not None:
+            self.heads["hi"] = self.heads["lo"] + self.heads["pad_rows"] * self.heads["cols"]
+            self.heads["bias_hi"] = bounds[0][1]          # [hi, bias_hi): the heads' biases
         self.offsets, self.total = offs, total
         self.buckets = [tuple(bounds[b]) for b in sorted(bounds)]
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -72,36 +92,42 @@ class FlatParameters:
 
 
 class GradientReducer:
-    """SUM all-reduce of FlatParameters.grad in buckets; `launch(b)` is asynchronous on RCCL's
-    stream (ordered after everything enqueued so far on the compute stream), `finish()` makes the
-    compute stream wait for all of them."""
+    """SUM all-reduce of ranges of FlatParameters.grad; `launch` is asynchronous on RCCL's stream (ordered after
+    everything enqueued so far on the current stream), `wait` makes the current stream wait for one of them.  Ranges are
+    named by a key: a bucket index of FlatParameters.buckets, or any hashable together with explicit bounds."""
 
     def __init__(self, flat: FlatParameters, process_group=None, force=False):
         self.flat, self.pg = flat, process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         # `force`: issue the collectives even in a one-rank group (a 1-GPU box then exercises the real RCCL calls)
         self.active = self.world > 1 or (force and dist.is_initialized())
         self.works = {}
-        self.launched = set()
 
-    def launch(self, bucket):
-        if not self.active or bucket in self.launched:
+    def launch(self, key, lo=None, hi=None):
+        if not self.active or key in self.works:
             return
-        lo, hi = self.flat.buckets[bucket]
-        self.launched.add(bucket)
-        self.works[bucket] = dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        if lo is None:
+            lo, hi = self.flat.buckets[key]
+        if hi > lo:
+            self.works[key] = dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    def all_gather(self, key, out, inp):
+        """Asynchronous all_gather_into_tensor under the same bookkeeping (`inp` may be this rank's block of `out`)."""
+        if self.active and key not in self.works:
+            self.works[key] = dist.all_gather_into_tensor(out, inp, group=self.pg, async_op=True)
 
     def launch_all(self):
         for b in range(len(self.flat.buckets)):
             self.launch(b)
 
-    def wait(self, bucket):
-        """Make the current stream wait for `bucket`'s all-reduce (no-op if it was not launched / world == 1)."""
-        if bucket in self.launched:
-            self.works.pop(bucket).wait()
-            self.launched.discard(bucket)
+    def wait(self, key):
+        """Make the current stream wait for `key`'s collective (no-op if it was not launched)."""
+        w = self.works.pop(key, None)
+        if w is not None:
+            w.wait()
 
     def finish(self):
         self.launch_all()
-        for b in list(self.launched):
-            self.wait(b)
+        for k in list(self.works):
+            self.wait(k)

@@ -201,6 +201,15 @@ long hp_hypernet_backward_workspace_floats(int B);
 int hp_hypernet_backward(int B, int in_size, const float* latent, const HpHyperWeights* w, const float* t,
                          const float* grad_theta, int theta_ld, const HpHyperGrads* grads, float* grad_latent /* or NULL */,
                          float* ws, hpStream_t stream);
+/* Data-parallel form of the heads' weight gradient (no counterpart in the reference, which has no distributed code:
+ * SURVEY 8e).  grads->head_w[0] == NULL makes hp_hypernet_backward skip dW of the heads (bias gradients and d latent are
+ * still produced); ranks then all-gather d theta (B x theta_ld) and t5 (B x 2048, hp_hypernet_t5_offset(B) floats into
+ * the forward's `t`) and each forms rows [r0, r0+rows) of the GLOBAL gradient of the (19011 x 2048) heads matrix:
+ *   dW_rows = dtheta_all[:, r0:r0+rows]^T . t5_all   (contraction over the Kc = world*B gathered clouds). */
+long hp_hypernet_t5_offset(int B);
+long hp_hypernet_heads_dw_workspace_floats(void);
+int hp_hypernet_heads_dw_rows(int Kc, int rows, int r0, const float* dtheta_all, int theta_ld, const float* t5_all,
+                              float* dW_rows, float* ws, hpStream_t stream);
 
 /* The B per-cloud TargetNetworks of one step at once (model/full_model.py:70-74, model/target_network.py:6-45).
  * theta (B,theta_ld): [W1 b1 | W2 b2 | ... | Wout bout] per cloud; pts (B,N,3) -> y (B,N,3) (rec[b] = y[b]^T).

@@ -39,7 +39,7 @@ def _build():
     return m.cuda()
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, shard):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "3d-point-clouds-autocomplete_amd")):
         if p not in sys.path:
@@ -53,7 +53,8 @@ def _worker(rank, world, port, out):
         with torch.no_grad():
             for p in model.parameters():
                 p.add_(0.01)
-    eng = TrainEngine(model, emd_coef=0.05)
+    eng = TrainEngine(model, emd_coef=0.05, shard_heads=shard)
+    assert (eng.shard is not None) == shard
     ex, mi, gt, pts, eps = (t.cuda() for t in _data())
     sl = slice(rank * 2, rank * 2 + 2)
     for _ in range(2):
@@ -67,7 +68,10 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_engine_matches_single_process_global_batch():
+@pytest.mark.parametrize("shard", [True, False], ids=["sharded-heads", "all-reduce"])
+def test_two_rank_engine_matches_single_process_global_batch(shard):
+    """Both exchanges of the heads' gradient: `shard` = ranks all-gather d theta / t5, each updates its row slice of the
+    heads and the updated rows are all-gathered (HeadsShard); otherwise the flat gradient is all-reduced."""
     from hyperpocket_amd import ops
     from hyperpocket_amd.core.engine import TrainEngine
     s = socket.socket()
@@ -77,7 +81,7 @@ def test_two_rank_engine_matches_single_process_global_batch():
     ctx = mp.get_context("spawn")
     import tempfile
     out = os.path.join(tempfile.mkdtemp(), "rank0_params.pt")
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, shard)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -99,3 +103,22 @@ def test_two_rank_engine_matches_single_process_global_batch():
             assert (a - b).abs().mean().item() <= 2e-6, k
     finally:
         ops.clear_grad_views()
+
+
+def test_heads_dw_rows_equals_slice_of_full_product():
+    """hp_hypernet_heads_dw_rows: rows [r0, r0+rows) of dtheta_all^T . t5_all, at the 8-rank shape (Kc = 8*64) and at a
+    ragged last slice."""
+    import ctypes
+    from hyperpocket_amd._lib import call, current_stream, load_library
+    lib = load_library()
+    lib.hp_hypernet_heads_dw_workspace_floats.restype = ctypes.c_long
+    g = torch.Generator().manual_seed(1)
+    for kc, r0, rows in ((512, 2377 * 3, 2377), (128, 19016 // 2, 19011 - 19016 // 2), (4, 0, 130)):
+        dth = torch.randn(kc, 19011, generator=g).cuda()
+        t5 = torch.randn(kc, 2048, generator=g).cuda()
+        out = torch.full((rows, 2048), float("nan"), device="cuda")
+        ws = torch.empty(lib.hp_hypernet_heads_dw_workspace_floats(), device="cuda")
+        call("hp_hypernet_heads_dw_rows", kc, rows, r0, dth, 19011, t5, out, ws, current_stream(out.device))
+        want = dth[:, r0:r0 + rows].double().t() @ t5.double()
+        err = (out.double() - want).abs().max().item()
+        assert err <= 2e-5 * want.abs().max().item(), (kc, r0, rows, err)

@@ -75,7 +75,14 @@ def test_flat_parameters_layout():
     before = {k: v.clone() for k, v in m.state_dict().items()}
     flat = FlatParameters(m)
     assert flat.is_intact()
-    assert flat.total >= 43328515 and flat.total - 43328515 < 4 * len(flat.params)
+    # padding: 16-byte alignment per parameter + the heads' matrix padded to a multiple of 8 rows (sharded heads update)
+    assert flat.total >= 43328515 and flat.total - 43328515 < 4 * len(flat.params) + 8 * 2048
+    h = flat.heads
+    assert h["rows"] == 19011 and h["pad_rows"] == 19016 and h["cols"] == 2048 and h["lo"] == 0
+    assert all(h["pad_rows"] % w == 0 for w in (1, 2, 4, 8))
+    assert flat.flat[h["rows"] * h["cols"]:h["hi"]].abs().sum().item() == 0.0        # pad rows are zero
+    names = dict(zip(flat.names, flat.offsets))
+    assert names["hyper_network.output.0.bias"] == h["hi"]                             # biases follow the padded matrix
     for k, v in m.state_dict().items():
         assert torch.equal(v, before[k])                 # values preserved, now views of one buffer
     # bucket order = the order backward produces gradients: heads, trunk, encoders
