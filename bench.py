@@ -61,7 +61,8 @@ def event_time_ms(fn, iters, warm=2):
     The events bracket back-to-back launches, so a host-side pause longer than the queued work would be counted as
     kernel time: Python's cyclic collector (a 30 ms gen-2 pass was observed here) is held off for the region.  The
     start event is recorded straight behind the warm-up launches, with no synchronisation in between: an idle gap there
-    makes the chip re-ramp its clock inside the timed region (measured: 102 vs 113-118 TFLOP/s on the same launches)."""
+    makes the chip re-ramp its clock inside the timed region (measured: 102 vs 113-118 TFLOP/s on the same launches at
+    20 warm-up launches)."""
     gc.collect()
     gc.disable()
     try:
@@ -90,7 +91,10 @@ def roofline_dominant_kernel(batch, n_half):
     w = torch.randn(512, 512, device="cuda") * 0.05
     b = torch.zeros(512, device="cuda")
     c = torch.empty(m, 512, device="cuda")
-    ms = event_time_ms(lambda: gemm(a, w, bias=b, out=c), iters=40, warm=20)
+    # 200 warm-up launches (~55 ms): the chip needs >20 ms of continuous load to reach the clock it then sustains — the
+    # state every kernel of a training run executes in (tools/roof_sweep.py: 20 warm-up launches read 112 TFLOP/s, 100,
+    # 400 or 2000 read 127 on the same box; the step time itself does not depend on the warm-up length)
+    ms = event_time_ms(lambda: gemm(a, w, bias=b, out=c), iters=100, warm=200)
     flops = 2.0 * m * 512 * 512
     achieved = flops / (ms * 1e-3) / 1e12
     traffic = None
