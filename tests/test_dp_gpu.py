@@ -122,3 +122,24 @@ def test_heads_dw_rows_equals_slice_of_full_product():
         want = dth[:, r0:r0 + rows].double().t() @ t5.double()
         err = (out.double() - want).abs().max().item()
         assert err <= 2e-5 * want.abs().max().item(), (kc, r0, rows, err)
+
+
+def test_bench_runs_every_collective_in_a_one_rank_rccl_group():
+    """bench.py with HP_BENCH_FORCE_EXCHANGE=1: a one-rank RCCL (backend "nccl") group in which the multi-rank step
+    really issues its collectives — broadcast, the d theta / t5 gathers, the in-place gather of the updated heads rows,
+    both all-reduces, the deferred waits, the barrier — on the production transport."""
+    import json
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HP_BENCH_FORCE_EXCHANGE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "2", "--batch", "8",
+                        "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["final_loss"] == line["final_loss"]
