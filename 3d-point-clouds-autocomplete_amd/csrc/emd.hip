@@ -305,7 +305,10 @@ __device__ __forceinline__ f2 match_entry2(f2 d, const float (&row)[kLevels], co
     for (int lev = 0; lev < kLevels; ++lev) {
         const f2 e = exp2_2(splat(level_l2e(lev)) * d);
         const f2 cr = FINC(lo, hi, 3 + lev);
-        acc += ROW_IS_L ? (e * splat(row[lev])) * cr : (e * cr) * splat(row[lev]);
+        // the level's term rides on an fma into the running sum (one rounding instead of the reference's two, i.e. a
+        // slightly more accurate M; unlike the phase sweeps nothing downstream amplifies it: cost moves by ~1e-7 relative)
+        acc = ROW_IS_L ? __builtin_elementwise_fma(e * splat(row[lev]), cr, acc)
+                       : __builtin_elementwise_fma(e * cr, splat(row[lev]), acc);
     }
     return acc;
 }
