@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_n1.json 2> $O/bench_n1.err
 python3 $R/bench.py --no-emd --no-cpu-baseline > $O/bench_chamfer.json 2>/dev/null
 python3 $R/bench.py --roofline-only > $O/roofline_events.json 2>/dev/null
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/step -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/step.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/step -- python3 $R/bench.py --steps 5 --warmup 2 --no-extras --no-cpu-baseline > $O/step.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/roof -- python3 $R/bench.py --roofline-only > $O/roof.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/roof_pmc_$c -- python3 $R/bench.py --roofline-only > /dev/null 2>&1
