@@ -176,7 +176,15 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            # RCCL's stream from the high-priority pool: its own hardware queue (never folded onto the compute stream's),
+            # and the few workgroups of a collective are dispatched ahead of the wide GEMMs' instead of queueing behind
+            opts = None
+            try:
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            except Exception:      # older binding: default stream priority
+                pass
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                    pg_options=opts)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     else:
