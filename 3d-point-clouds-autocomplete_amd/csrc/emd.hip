@@ -25,6 +25,7 @@
 //   * padding records carry zero weights and contribute exact zeros.
 #include "hp_common.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -141,29 +142,41 @@ __device__ __forceinline__ f2 exp2_2(f2 a) { return f2{__builtin_amdgcn_exp2f(a.
 
 // Rows = set1.  DO3: phase 3 of level lev3 (remainL update, approxmatch.cu:161-194);
 //               DO1: phase 1 of level lev1 (ratioL, :60-93).  Candidates: PRP (+RR) records on the scalar path.
-template <bool DO3, bool DO1>
+// R rows per lane, as in emd_rows2_kernel.
+template <bool DO3, bool DO1, int R>
 __global__ __launch_bounds__(kThreads) void emd_rows1_kernel(Ctx c, int lev1, float l2e3, float l2e1) {
-    __shared__ float part3[kParts][kRowsPerWg], part1[kParts][kRowsPerWg];
+    __shared__ float part3[kParts][kRowsPerWg * R], part1[kParts][kRowsPerWg * R];
     const int cloud = blockIdx.y;
     const int lrow = threadIdx.x % kRowsPerWg;
     const int part = __builtin_amdgcn_readfirstlane(threadIdx.x / kRowsPerWg);   // wave-uniform
-    const int k = blockIdx.x * kRowsPerWg + lrow;
     float* ws = c.ws + (long)cloud * c.per_cloud;
     float* remL = c.temp + (long)cloud * (c.n + c.m) * 2;
     float* ratioL = remL + c.n + c.m;
-    const bool ok = k < c.n;
-    float px = 0.f, py = 0.f, pz = 0.f, rl = 0.f;
-    if (ok) {
-        const float* s = c.xyz1 + ((long)cloud * c.n + k) * 3;
-        px = s[0];
-        py = s[1];
-        pz = s[2];
-        if (DO3) rl = ratioL[k];
+    int k[R];
+    bool ok[R];
+    f2 px2[R], py2[R], pz2[R], rl2[R], acc3[R], acc1[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        k[r] = (blockIdx.x * R + r) * kRowsPerWg + lrow;
+        ok[r] = k[r] < c.n;
+        float px = 0.f, py = 0.f, pz = 0.f, rl = 0.f;
+        if (ok[r]) {
+            const float* s = c.xyz1 + ((long)cloud * c.n + k[r]) * 3;
+            px = s[0];
+            py = s[1];
+            pz = s[2];
+            if (DO3) rl = ratioL[k[r]];
+        }
+        px2[r] = splat(px);
+        py2[r] = splat(py);
+        pz2[r] = splat(pz);
+        rl2[r] = splat(rl);
+        // even / odd candidates accumulate in the two halves of a packed register (one v_pk_add_f32 per pair record
+        // instead of two dependent v_add_f32); the halves are added once at the end, then the 4 candidate ranges in order
+        acc3[r] = splat(0.f);
+        acc1[r] = f2{part == 0 ? 1e-9f : 0.f, 0.f};
     }
-    const f2 px2 = splat(px), py2 = splat(py), pz2 = splat(pz), rl2 = splat(rl), l3 = splat(l2e3), l1 = splat(l2e1);
-    // even / odd candidates accumulate in the two halves of a packed register (one v_pk_add_f32 per pair record instead
-    // of two dependent v_add_f32); the halves are added once at the end, then the 4 candidate ranges in range order
-    f2 acc3 = splat(0.f), acc1 = f2{part == 0 ? 1e-9f : 0.f, 0.f};
+    const f2 l3 = splat(l2e3), l1 = splat(l2e1);
     const int cand = c.MP / kParts;                                  // candidates of this wave's range
     const float* p = ws + c.prp + (long)part * cand * 4;   // wave-uniform
     const float* q = ws + c.rr + (long)part * cand;
@@ -172,12 +185,15 @@ __global__ __launch_bounds__(kThreads) void emd_rows1_kernel(Ctx c, int lev1, fl
     auto work = [&](const f32x16& lo, const f32x16& hi, const f32x8& w) {
 #pragma unroll
         for (int u = 0; u < kStage / 2; ++u) {
-            const f2 d = sqdist2(PAIRC(lo, hi, u, 0) - px2, PAIRC(lo, hi, u, 1) - py2, PAIRC(lo, hi, u, 2) - pz2);
-            if (DO3) {
-                acc3 += (exp2_2(l3 * d) * rl2) * PAIRC(lo, hi, u, 3);   // (e * ratioL[k]) * ratioR[l]
-            }
-            if (DO1) {
-                acc1 += exp2_2(l1 * d) * f2{w[u * 2], w[u * 2 + 1]};   // e * remainR[l]
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const f2 d = sqdist2(PAIRC(lo, hi, u, 0) - px2[r], PAIRC(lo, hi, u, 1) - py2[r], PAIRC(lo, hi, u, 2) - pz2[r]);
+                if (DO3) {
+                    acc3[r] += (exp2_2(l3 * d) * rl2[r]) * PAIRC(lo, hi, u, 3);   // (e * ratioL[k]) * ratioR[l]
+                }
+                if (DO1) {
+                    acc1[r] += exp2_2(l1 * d) * f2{w[u * 2], w[u * 2 + 1]};   // e * remainR[l]
+                }
             }
         }
     };
@@ -193,7 +209,7 @@ __global__ __launch_bounds__(kThreads) void emd_rows1_kernel(Ctx c, int lev1, fl
         if (DO1) HP_SLOAD8(w1, q, 0x0);
         HP_PIN();
         work(a0, a1, w0);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1), "+s"(w1), "+v"(acc3), "+v"(acc1));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1), "+s"(w1), "+v"(acc3[0]), "+v"(acc1[0]), "+v"(acc3[R - 1]), "+v"(acc1[R - 1]));
         p += kStage * 4;
         q += kStage;
         HP_SLOAD16(a0, p, 0x0);      // past the last stage this reads the spare (zero) records
@@ -201,60 +217,86 @@ __global__ __launch_bounds__(kThreads) void emd_rows1_kernel(Ctx c, int lev1, fl
         if (DO1) HP_SLOAD8(w0, q, 0x0);
         HP_PIN();
         work(b0, b1, w1);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+s"(w0), "+v"(acc3), "+v"(acc1));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+s"(w0), "+v"(acc3[0]), "+v"(acc1[0]), "+v"(acc3[R - 1]), "+v"(acc1[R - 1]));
     }
-    float s3 = acc3.x + acc3.y, s1 = acc1.x + acc1.y;
-    part3[part][lrow] = s3;
-    part1[part][lrow] = s1;
-    __syncthreads();
-    if (part != 0 || !ok) return;
+    float s3[R], s1[R];
 #pragma unroll
-    for (int q2 = 1; q2 < kParts; ++q2) {
-        s3 += part3[q2][lrow];
-        s1 += part1[q2][lrow];
+    for (int r = 0; r < R; ++r) {
+        s3[r] = acc3[r].x + acc3[r].y;
+        s1[r] = acc1[r].x + acc1[r].y;
+        part3[part][r * kRowsPerWg + lrow] = s3[r];
+        part1[part][r * kRowsPerWg + lrow] = s1[r];
     }
-    float rem = remL[k];
-    if (DO3) {
-        rem = fmaxf(0.0f, rem - s3);
-        remL[k] = rem;
-    }
-    if (DO1) {
-        const float v = rem / s1;
-        ratioL[k] = v;
-        ws[c.plp + pair8(k, 3)] = v;
-        ws[c.flp + pair32(k, 3 + lev1)] = v;
+    __syncthreads();
+    if (part != 0) return;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (!ok[r]) continue;
+        float t3 = s3[r], t1 = s1[r];
+#pragma unroll
+        for (int q2 = 1; q2 < kParts; ++q2) {
+            t3 += part3[q2][r * kRowsPerWg + lrow];
+            t1 += part1[q2][r * kRowsPerWg + lrow];
+        }
+        float rem = remL[k[r]];
+        if (DO3) {
+            rem = fmaxf(0.0f, rem - t3);
+            remL[k[r]] = rem;
+        }
+        if (DO1) {
+            const float v = rem / t1;
+            ratioL[k[r]] = v;
+            ws[c.plp + pair8(k[r], 3)] = v;
+            ws[c.flp + pair32(k[r], 3 + lev1)] = v;
+        }
     }
 }
 
 // Rows = set2: phase 2 (ratioR / remainR update, approxmatch.cu:109-142).  Candidates: PLP records.
+// R rows per lane (rows l and l + 64, ...): every candidate record fetched on the scalar path serves R rows, so a stage
+// carries R times the VALU work behind its s_waitcnt (R independent accumulation chains per lane) at 1/R of the scalar
+// traffic.  Per row the arithmetic and its order are those of R = 1.
+template <int R>
 __global__ __launch_bounds__(kThreads) void emd_rows2_kernel(Ctx c, int lev, float l2e) {
-    __shared__ float parts[kParts][kRowsPerWg];
+    __shared__ float parts[kParts][kRowsPerWg * R];
     const int cloud = blockIdx.y;
     const int lrow = threadIdx.x % kRowsPerWg;
     const int part = __builtin_amdgcn_readfirstlane(threadIdx.x / kRowsPerWg);
-    const int l = blockIdx.x * kRowsPerWg + lrow;
     float* ws = c.ws + (long)cloud * c.per_cloud;
     float* remR = c.temp + (long)cloud * (c.n + c.m) * 2 + c.n;
     float* ratioR = remR + c.m + c.n;
-    const bool ok = l < c.m;
-    float qx = 0.f, qy = 0.f, qz = 0.f;
-    if (ok) {
-        const float* s = c.xyz2 + ((long)cloud * c.m + l) * 3;
-        qx = s[0];
-        qy = s[1];
-        qz = s[2];
+    int l[R];
+    bool ok[R];
+    f2 qx2[R], qy2[R], qz2[R], acc2[R];   // acc2: even / odd candidates (see emd_rows1_kernel)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        l[r] = (blockIdx.x * R + r) * kRowsPerWg + lrow;
+        ok[r] = l[r] < c.m;
+        float qx = 0.f, qy = 0.f, qz = 0.f;
+        if (ok[r]) {
+            const float* s = c.xyz2 + ((long)cloud * c.m + l[r]) * 3;
+            qx = s[0];
+            qy = s[1];
+            qz = s[2];
+        }
+        qx2[r] = splat(qx);
+        qy2[r] = splat(qy);
+        qz2[r] = splat(qz);
+        acc2[r] = splat(0.f);
     }
-    const f2 qx2 = splat(qx), qy2 = splat(qy), qz2 = splat(qz), lv = splat(l2e);
-    f2 acc2 = splat(0.f);   // even / odd candidates (see emd_rows1_kernel)
+    const f2 lv = splat(l2e);
     const int cand = c.NP / kParts;
     const float* p = ws + c.plp + (long)part * cand * 4;
     f32x16 a0, a1, b0, b1;
     auto work = [&](const f32x16& lo, const f32x16& hi) {
 #pragma unroll
         for (int u = 0; u < kStage / 2; ++u) {
-            // the reference evaluates (x2-x1) with x2 the set2 point in every phase (approxmatch.cu:85,131,185)
-            const f2 d = sqdist2(qx2 - PAIRC(lo, hi, u, 0), qy2 - PAIRC(lo, hi, u, 1), qz2 - PAIRC(lo, hi, u, 2));
-            acc2 += exp2_2(lv * d) * PAIRC(lo, hi, u, 3);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                // the reference evaluates (x2-x1) with x2 the set2 point in every phase (approxmatch.cu:85,131,185)
+                const f2 d = sqdist2(qx2[r] - PAIRC(lo, hi, u, 0), qy2[r] - PAIRC(lo, hi, u, 1), qz2[r] - PAIRC(lo, hi, u, 2));
+                acc2[r] += exp2_2(lv * d) * PAIRC(lo, hi, u, 3);
+            }
         }
     };
     HP_SLOAD16(a0, p, 0x0);
@@ -266,30 +308,41 @@ __global__ __launch_bounds__(kThreads) void emd_rows2_kernel(Ctx c, int lev, flo
         HP_SLOAD16(b1, p, 0x40);
         HP_PIN();
         work(a0, a1);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1), "+v"(acc2));
+        if (R == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1), "+v"(acc2[0]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1), "+v"(acc2[0]), "+v"(acc2[R - 1]));
         p += kStage * 4;
         HP_SLOAD16(a0, p, 0x0);
         HP_SLOAD16(a1, p, 0x40);
         HP_PIN();
         work(b0, b1);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(acc2));
+        if (R == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(acc2[0]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(acc2[0]), "+v"(acc2[R - 1]));
     }
-    float acc = acc2.x + acc2.y;
-    parts[part][lrow] = acc;
-    __syncthreads();
-    if (part != 0 || !ok) return;
+    float acc[R];
 #pragma unroll
-    for (int q2 = 1; q2 < kParts; ++q2) acc += parts[q2][lrow];
-    const float rr = remR[l];
-    const float sumr = acc * rr;
-    const float consumption = fminf(rr / (sumr + 1e-9f), 1.0f);
-    const float v = consumption * rr;
-    const float rem = fmaxf(0.0f, rr - sumr);
-    ratioR[l] = v;
-    remR[l] = rem;
-    ws[c.prp + pair8(l, 3)] = v;
-    ws[c.rr + l] = rem;
-    ws[c.frp + pair32(l, 3 + lev)] = v;
+    for (int r = 0; r < R; ++r) {
+        acc[r] = acc2[r].x + acc2[r].y;
+        parts[part][r * kRowsPerWg + lrow] = acc[r];
+    }
+    __syncthreads();
+    if (part != 0) return;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (!ok[r]) continue;
+        float a = acc[r];
+#pragma unroll
+        for (int q2 = 1; q2 < kParts; ++q2) a += parts[q2][r * kRowsPerWg + lrow];
+        const float rr = remR[l[r]];
+        const float sumr = a * rr;
+        const float consumption = fminf(rr / (sumr + 1e-9f), 1.0f);
+        const float v = consumption * rr;
+        const float rem = fmaxf(0.0f, rr - sumr);
+        ratioR[l[r]] = v;
+        remR[l[r]] = rem;
+        ws[c.prp + pair8(l[r], 3)] = v;
+        ws[c.rr + l[r]] = rem;
+        ws[c.frp + pair32(l[r], 3 + lev)] = v;
+    }
 }
 
 // final pair record (two x16 SGPR groups): component q (0..2 xyz, 3+lev ratio) as a float2
@@ -528,16 +581,40 @@ int run_levels(int b, int n, int m, const float* xyz1, const float* xyz2, float*
         multiR = 1;
     }
     const dim3 g1((n + kRowsPerWg - 1) / kRowsPerWg, b), g2((m + kRowsPerWg - 1) / kRowsPerWg, b);
+    const dim3 g2r((m + 2 * kRowsPerWg - 1) / (2 * kRowsPerWg), b), g2q((m + 4 * kRowsPerWg - 1) / (4 * kRowsPerWg), b);
+    const dim3 g1r((n + 2 * kRowsPerWg - 1) / (2 * kRowsPerWg), b), g1q((n + 4 * kRowsPerWg - 1) / (4 * kRowsPerWg), b);
+    // rows per lane: the most that still leaves >= 2 waves per SIMD on the chip (measured at B=64, N=2048 on the whole
+    // step: phase 1/3 kernel best at 2 — 4 costs occupancy it needs —, phase 2 at 4: -0.10 ms together; tools/emd_rows_sweep.sh).
+    // HP_EMD_ROWS1_R / HP_EMD_ROWS2_R override (experiments).
+    auto pick = [&](int rows, int cap) {
+        for (int r = cap; r > 1; r >>= 1)
+            if ((long)b * ((rows + r * kRowsPerWg - 1) / (r * kRowsPerWg)) * (kThreads / 64) >= 2048) return r;
+        return 1;
+    };
+    static const int env1 = getenv("HP_EMD_ROWS1_R") ? atoi(getenv("HP_EMD_ROWS1_R")) : 0;
+    static const int env2 = getenv("HP_EMD_ROWS2_R") ? atoi(getenv("HP_EMD_ROWS2_R")) : 0;
+    const int rows1_r = env1 ? env1 : pick(n, 2), rows2_r = env2 ? env2 : pick(m, 4);
     hipLaunchKernelGGL(emd_init_kernel, dim3((L.NP + L.MP + 2 * kSpare + kThreads - 1) / kThreads, b), dim3(kThreads), 0, stream, c, multiL, multiR);
-    hipLaunchKernelGGL((emd_rows1_kernel<false, true>), g1, dim3(kThreads), 0, stream, c, 0, 0.f, level_l2e(0));
+#define HP_ROWS1(D3, D1, ...)                                                                                          \
+    do {                                                                                                                \
+        if (rows1_r == 4) hipLaunchKernelGGL((emd_rows1_kernel<D3, D1, 4>), g1q, dim3(kThreads), 0, stream, __VA_ARGS__); \
+        else if (rows1_r == 2) hipLaunchKernelGGL((emd_rows1_kernel<D3, D1, 2>), g1r, dim3(kThreads), 0, stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL((emd_rows1_kernel<D3, D1, 1>), g1, dim3(kThreads), 0, stream, __VA_ARGS__);              \
+    } while (0)
+    HP_ROWS1(false, true, c, 0, 0.f, level_l2e(0));
     for (int lev = 0; lev < kLevels; ++lev) {
-        hipLaunchKernelGGL(emd_rows2_kernel, g2, dim3(kThreads), 0, stream, c, lev, level_l2e(lev));
-        if (lev + 1 < kLevels)
-            hipLaunchKernelGGL((emd_rows1_kernel<true, true>), g1, dim3(kThreads), 0, stream, c, lev + 1, level_l2e(lev),
-                               level_l2e(lev + 1));
+        if (rows2_r == 4)
+            hipLaunchKernelGGL(emd_rows2_kernel<4>, g2q, dim3(kThreads), 0, stream, c, lev, level_l2e(lev));
+        else if (rows2_r == 2)
+            hipLaunchKernelGGL(emd_rows2_kernel<2>, g2r, dim3(kThreads), 0, stream, c, lev, level_l2e(lev));
         else
-            hipLaunchKernelGGL((emd_rows1_kernel<true, false>), g1, dim3(kThreads), 0, stream, c, lev, level_l2e(lev), 0.f);
+            hipLaunchKernelGGL(emd_rows2_kernel<1>, g2, dim3(kThreads), 0, stream, c, lev, level_l2e(lev));
+        if (lev + 1 < kLevels)
+            HP_ROWS1(true, true, c, lev + 1, level_l2e(lev), level_l2e(lev + 1));
+        else
+            HP_ROWS1(true, false, c, lev, level_l2e(lev), 0.f);
     }
+#undef HP_ROWS1
     *out = c;
     return (int)hipGetLastError();
 }
