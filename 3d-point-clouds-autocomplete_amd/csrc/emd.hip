@@ -488,30 +488,44 @@ __global__ __launch_bounds__(kThreads) void emd_cost_grad1_kernel(Ctx c, float* 
 // match-free grad2[l] = sum_k M(l,k) (q_l-p_k)/max(|q_l-p_k|,1e-10)   (approxmatch.cu:260-300); with WITH_COST the
 // same sweep also yields the cost (sum over the same pairs, owned by l instead of k), so a training step that only
 // needs d cost / d xyz2 evaluates the match entries once.
-template <bool WITH_COST>
+template <bool WITH_COST, int R>
 __global__ __launch_bounds__(kThreads) void emd_grad2_kernel(Ctx c, float* __restrict__ grad2, float* __restrict__ partials) {
     __shared__ float red[kThreads / 64];
-    __shared__ float parts[kParts][4][kRowsPerWg];
+    __shared__ float parts[kParts][4][kRowsPerWg * R];
     const int cloud = blockIdx.y;
     const int lrow = threadIdx.x % kRowsPerWg;
     const int part = __builtin_amdgcn_readfirstlane(threadIdx.x / kRowsPerWg);
-    const int l = blockIdx.x * kRowsPerWg + lrow;
     const float* ws = c.ws + (long)cloud * c.per_cloud;
-    const bool ok = l < c.m;
-    float qx = 0.f, qy = 0.f, qz = 0.f, rR[kLevels] = {};
-    if (ok) load_row_final(ws + c.frp, l, qx, qy, qz, rR);
-    const f2 qx2 = splat(qx), qy2 = splat(qy), qz2 = splat(qz);
-    f2 sx2 = splat(0.f), sy2 = splat(0.f), sz2 = splat(0.f), cost2 = splat(0.f);   // even / odd candidates (see emd_rows1_kernel)
+    int l[R];
+    bool ok[R];
+    float rR[R][kLevels];
+    f2 qx2[R], qy2[R], qz2[R], sx2[R], sy2[R], sz2[R], cost2[R];   // sums: even / odd candidates (see emd_rows1_kernel)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        l[r] = (blockIdx.x * R + r) * kRowsPerWg + lrow;
+        ok[r] = l[r] < c.m;
+        float qx = 0.f, qy = 0.f, qz = 0.f;
+#pragma unroll
+        for (int lev = 0; lev < kLevels; ++lev) rR[r][lev] = 0.f;
+        if (ok[r]) load_row_final(ws + c.frp, l[r], qx, qy, qz, rR[r]);
+        qx2[r] = splat(qx);
+        qy2[r] = splat(qy);
+        qz2[r] = splat(qz);
+        sx2[r] = sy2[r] = sz2[r] = cost2[r] = splat(0.f);
+    }
     auto work = [&](const f32x16& lo, const f32x16& hi) {
-        const f2 ex = qx2 - FINC(lo, hi, 0), ey = qy2 - FINC(lo, hi, 1), ez = qz2 - FINC(lo, hi, 2);
-        const f2 d2 = sqdist2(ex, ey, ez);
-        const f2 mv = match_entry2<false>(d2, rR, lo, hi);
-        const f2 w = mv * f2{__builtin_amdgcn_rsqf(fmaxf(d2.x, 1e-20f)), __builtin_amdgcn_rsqf(fmaxf(d2.y, 1e-20f))};
-        if (WITH_COST)
-            cost2 = __builtin_elementwise_fma(mv, f2{__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)}, cost2);
-        sx2 = __builtin_elementwise_fma(ex, w, sx2);
-        sy2 = __builtin_elementwise_fma(ey, w, sy2);
-        sz2 = __builtin_elementwise_fma(ez, w, sz2);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const f2 ex = qx2[r] - FINC(lo, hi, 0), ey = qy2[r] - FINC(lo, hi, 1), ez = qz2[r] - FINC(lo, hi, 2);
+            const f2 d2 = sqdist2(ex, ey, ez);
+            const f2 mv = match_entry2<false>(d2, rR[r], lo, hi);
+            const f2 w = mv * f2{__builtin_amdgcn_rsqf(fmaxf(d2.x, 1e-20f)), __builtin_amdgcn_rsqf(fmaxf(d2.y, 1e-20f))};
+            if (WITH_COST)
+                cost2[r] = __builtin_elementwise_fma(mv, f2{__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)}, cost2[r]);
+            sx2[r] = __builtin_elementwise_fma(ex, w, sx2[r]);
+            sy2[r] = __builtin_elementwise_fma(ey, w, sy2[r]);
+            sz2[r] = __builtin_elementwise_fma(ez, w, sz2[r]);
+        }
     };
     const int cand = c.NP / kParts;
     const float* p = ws + c.flp + (long)part * cand * 16;
@@ -525,37 +539,51 @@ __global__ __launch_bounds__(kThreads) void emd_grad2_kernel(Ctx c, float* __res
         HP_SLOAD16(b1, p, 0x40);
         HP_PIN();
         work(a0, a1);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1), "+v"(sx2), "+v"(sy2), "+v"(sz2), "+v"(cost2));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1), "+v"(sx2[0]), "+v"(sy2[0]), "+v"(sz2[0]), "+v"(cost2[0]),
+                     "+v"(sx2[R - 1]), "+v"(sy2[R - 1]), "+v"(sz2[R - 1]), "+v"(cost2[R - 1]));
         p += 32;
         HP_SLOAD16(a0, p, 0x0);
         HP_SLOAD16(a1, p, 0x40);
         HP_PIN();
         work(b0, b1);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(sx2), "+v"(sy2), "+v"(sz2), "+v"(cost2));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(sx2[0]), "+v"(sy2[0]), "+v"(sz2[0]), "+v"(cost2[0]),
+                     "+v"(sx2[R - 1]), "+v"(sy2[R - 1]), "+v"(sz2[R - 1]), "+v"(cost2[R - 1]));
     }
-    float sx = sx2.x + sx2.y, sy = sy2.x + sy2.y, sz = sz2.x + sz2.y, cost = cost2.x + cost2.y;
-    parts[part][0][lrow] = sx;
-    parts[part][1][lrow] = sy;
-    parts[part][2][lrow] = sz;
-    parts[part][3][lrow] = cost;
+    float sx[R], sy[R], sz[R], cost[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        sx[r] = sx2[r].x + sx2[r].y;
+        sy[r] = sy2[r].x + sy2[r].y;
+        sz[r] = sz2[r].x + sz2[r].y;
+        cost[r] = cost2[r].x + cost2[r].y;
+        parts[part][0][r * kRowsPerWg + lrow] = sx[r];
+        parts[part][1][r * kRowsPerWg + lrow] = sy[r];
+        parts[part][2][r * kRowsPerWg + lrow] = sz[r];
+        parts[part][3][r * kRowsPerWg + lrow] = cost[r];
+    }
     __syncthreads();
+    float total = 0.f;
     if (part == 0) {
 #pragma unroll
-        for (int q2 = 1; q2 < kParts; ++q2) {   // candidate ranges in ascending order
-            sx += parts[q2][0][lrow];
-            sy += parts[q2][1][lrow];
-            sz += parts[q2][2][lrow];
-            cost += parts[q2][3][lrow];
-        }
-        if (ok) {
-            float* g = grad2 + ((long)cloud * c.m + l) * 3;
-            g[0] = sx;
-            g[1] = sy;
-            g[2] = sz;
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int q2 = 1; q2 < kParts; ++q2) {   // candidate ranges in ascending order
+                sx[r] += parts[q2][0][r * kRowsPerWg + lrow];
+                sy[r] += parts[q2][1][r * kRowsPerWg + lrow];
+                sz[r] += parts[q2][2][r * kRowsPerWg + lrow];
+                cost[r] += parts[q2][3][r * kRowsPerWg + lrow];
+            }
+            if (ok[r]) {
+                float* g = grad2 + ((long)cloud * c.m + l[r]) * 3;
+                g[0] = sx[r];
+                g[1] = sy[r];
+                g[2] = sz[r];
+                total += cost[r];
+            }
         }
     }
     if (WITH_COST) {
-        const float t = hp::block_sum((ok && part == 0) ? cost : 0.f, red);
+        const float t = hp::block_sum(total, red);
         if (threadIdx.x == 0) partials[(long)cloud * gridDim.x + blockIdx.x] = t;
     }
 }
@@ -656,8 +684,17 @@ HP_API int hp_emd_forward(int b, int n, int m, const float* xyz1, const float* x
     if (rc) return rc;
     const int nb = (n + kRowsPerWg - 1) / kRowsPerWg, mb = (m + kRowsPerWg - 1) / kRowsPerWg;
     if (grad2) {
-        hipLaunchKernelGGL(emd_grad2_kernel<true>, dim3(mb, b), dim3(kThreads), 0, stream, c, grad2, partials);
-        hipLaunchKernelGGL(emd_cost_finish_kernel, dim3(b), dim3(256), 0, stream, partials, mb, cost);
+        static const int genv = getenv("HP_EMD_GRAD2_R") ? atoi(getenv("HP_EMD_GRAD2_R")) : 0;
+        const int mbr = (m + 2 * kRowsPerWg - 1) / (2 * kRowsPerWg);
+        // two rows per lane when that still leaves >= 2 waves per SIMD (as in run_levels; -0.01 ms at B=64, N=2048)
+        const int gr = genv ? genv : ((long)b * mbr * (kThreads / 64) >= 2048 ? 2 : 1);
+        if (gr == 2) {
+            hipLaunchKernelGGL((emd_grad2_kernel<true, 2>), dim3(mbr, b), dim3(kThreads), 0, stream, c, grad2, partials);
+            hipLaunchKernelGGL(emd_cost_finish_kernel, dim3(b), dim3(256), 0, stream, partials, mbr, cost);
+        } else {
+            hipLaunchKernelGGL((emd_grad2_kernel<true, 1>), dim3(mb, b), dim3(kThreads), 0, stream, c, grad2, partials);
+            hipLaunchKernelGGL(emd_cost_finish_kernel, dim3(b), dim3(256), 0, stream, partials, mb, cost);
+        }
         if (grad1) hipLaunchKernelGGL(emd_cost_grad1_kernel, dim3(nb, b), dim3(kThreads), 0, stream, c, partials, grad1);
         // (the second sweep's partials are unused: cost was already reduced, in stream order, by the finish kernel)
     } else {
@@ -675,6 +712,6 @@ HP_API int hp_emd_backward(int b, int n, int m, const float* xyz1, const float* 
     HP_CHECK_ARG(ws && grad2 && b <= 65535);
     const WsLayout L = ws_layout(n, m);
     Ctx c{n, m, L.NP, L.MP, xyz1, xyz2, nullptr, const_cast<float*>(ws), L.plp, L.prp, L.rr, L.flp, L.frp, L.per_cloud};
-    hipLaunchKernelGGL(emd_grad2_kernel<false>, dim3((m + kRowsPerWg - 1) / kRowsPerWg, b), dim3(kThreads), 0, stream, c, grad2, nullptr);
+    hipLaunchKernelGGL((emd_grad2_kernel<false, 1>), dim3((m + kRowsPerWg - 1) / kRowsPerWg, b), dim3(kThreads), 0, stream, c, grad2, nullptr);
     HP_RETURN_LAST_ERROR();
 }
