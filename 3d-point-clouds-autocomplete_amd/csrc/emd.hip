@@ -25,6 +25,7 @@
 //   * padding records carry zero weights and contribute exact zeros.
 #include "hp_common.h"
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 namespace {
@@ -80,6 +81,14 @@ inline WsLayout ws_layout(int n, int m) {
     w.per_cloud = w.frp + (long)(w.MP + kSpare) * 16;
     return w;
 }
+
+// forced rows-per-lane of the three sweep families (0 = the size heuristic); see hp_emd_set_rows_per_lane
+inline int env_rows(const char* name) {
+    const char* e = getenv(name);
+    const int v = e ? atoi(e) : 0;
+    return (v == 1 || v == 2 || v == 4) ? v : 0;
+}
+std::atomic<int> g_rows1{env_rows("HP_EMD_ROWS1_R")}, g_rows2{env_rows("HP_EMD_ROWS2_R")}, g_grad2{env_rows("HP_EMD_GRAD2_R") == 4 ? 0 : env_rows("HP_EMD_GRAD2_R")};
 
 struct Ctx {
     int n, m, NP, MP;
@@ -613,15 +622,15 @@ int run_levels(int b, int n, int m, const float* xyz1, const float* xyz2, float*
     const dim3 g1r((n + 2 * kRowsPerWg - 1) / (2 * kRowsPerWg), b), g1q((n + 4 * kRowsPerWg - 1) / (4 * kRowsPerWg), b);
     // rows per lane: the most that still leaves >= 2 waves per SIMD on the chip (measured at B=64, N=2048 on the whole
     // step: phase 1/3 kernel best at 2 — 4 costs occupancy it needs —, phase 2 at 4: -0.10 ms together; tools/emd_rows_sweep.sh).
-    // HP_EMD_ROWS1_R / HP_EMD_ROWS2_R override (experiments).
+    // hp_emd_set_rows_per_lane (or HP_EMD_ROWS1_R / HP_EMD_ROWS2_R at load time) overrides: every instance is a
+    // per-row-identical evaluation (tests/test_structural_losses_gpu.py compares them bit for bit and with the oracle).
     auto pick = [&](int rows, int cap) {
         for (int r = cap; r > 1; r >>= 1)
             if ((long)b * ((rows + r * kRowsPerWg - 1) / (r * kRowsPerWg)) * (kThreads / 64) >= 2048) return r;
         return 1;
     };
-    static const int env1 = getenv("HP_EMD_ROWS1_R") ? atoi(getenv("HP_EMD_ROWS1_R")) : 0;
-    static const int env2 = getenv("HP_EMD_ROWS2_R") ? atoi(getenv("HP_EMD_ROWS2_R")) : 0;
-    const int rows1_r = env1 ? env1 : pick(n, 2), rows2_r = env2 ? env2 : pick(m, 4);
+    const int f1 = g_rows1.load(std::memory_order_relaxed), f2 = g_rows2.load(std::memory_order_relaxed);
+    const int rows1_r = f1 ? f1 : pick(n, 2), rows2_r = f2 ? f2 : pick(m, 4);
     hipLaunchKernelGGL(emd_init_kernel, dim3((L.NP + L.MP + 2 * kSpare + kThreads - 1) / kThreads, b), dim3(kThreads), 0, stream, c, multiL, multiR);
 #define HP_ROWS1(D3, D1, ...)                                                                                          \
     do {                                                                                                                \
@@ -647,15 +656,137 @@ int run_levels(int b, int n, int m, const float* xyz1, const float* xyz2, float*
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Workspace-free path: the reference launcher's exact prototype (structural_loss.cpp:11), for callers that own
+// nothing but `match` and `temp`.  It keeps the reference's data flow (approxmatch.cu:34-213): the four vectors of
+// `temp` are the only state, every phase re-reads the other set's points and one of those vectors through a 16 KB LDS
+// tile, phase 3 read-modify-writes `match` once per level.  One lane per row; a row's sum runs over the candidates in
+// ascending order in one fp32 accumulator — the reference's per-thread order (:77-93,:125-137,:177-189), which also
+// makes this path comparable with the CPU oracle term by term.  ~2.5x the time of the record-based path at B=64,
+// N=2048 (it moves the 18 GB the reference moves); a binding that can allocate scratch calls hp_approxmatch_ws.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPlainTile = 1024;
+
+__global__ __launch_bounds__(kThreads) void emd_plain_init_kernel(int n, int m, float* __restrict__ temp, float multiL, float multiR) {
+    float* remL = temp + (long)blockIdx.y * (n + m) * 2;
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n + m; i += gridDim.x * kThreads) remL[i] = i < n ? multiL : multiR;
+}
+
+// PHASE 1: rows = set1, ratioL[k] = remainL[k] / (1e-9 + sum_l e * remainR[l])                     (:60-93)
+// PHASE 2: rows = set2, sumr = remainR[l] * sum_k e * ratioL[k]; ratioR / remainR update            (:109-142)
+// PHASE 3: rows = set1, w = (e * ratioL[k]) * ratioR[l]; match[l,k] += w; remainL[k] -= sum_l w    (:161-194)
+template <int PHASE>
+__global__ __launch_bounds__(kThreads) void emd_plain_kernel(int n, int m, const float* __restrict__ xyz1, const float* __restrict__ xyz2,
+                                                             float* __restrict__ temp, float* __restrict__ match, float l2e, int first) {
+    __shared__ float4 tile[kPlainTile];
+    const int cloud = blockIdx.y, tid = threadIdx.x;
+    float* remL = temp + (long)cloud * (n + m) * 2;
+    float* remR = remL + n;
+    float* ratioL = remR + m;
+    float* ratioR = ratioL + n;
+    constexpr bool kRowsL = PHASE != 2;
+    const int rows = kRowsL ? n : m, cands = kRowsL ? m : n;
+    const float* R = (kRowsL ? xyz1 : xyz2) + (long)cloud * rows * 3;
+    const float* C = (kRowsL ? xyz2 : xyz1) + (long)cloud * cands * 3;
+    const float* cw = PHASE == 1 ? remR : PHASE == 2 ? ratioL : ratioR;
+    const int row = blockIdx.x * kThreads + tid;
+    const bool ok = row < rows;
+    float rx = 0.f, ry = 0.f, rz = 0.f, rl = 0.f;
+    if (ok) {
+        rx = R[row * 3];
+        ry = R[row * 3 + 1];
+        rz = R[row * 3 + 2];
+        if (PHASE == 3) rl = ratioL[row];
+    }
+    float sum = PHASE == 1 ? 1e-9f : 0.f;
+    float* mcol = match + (long)cloud * m * n + row;
+    for (int c0 = 0; c0 < cands; c0 += kPlainTile) {
+        const int cnt = min(kPlainTile, cands - c0);
+        for (int t = tid; t < cnt; t += kThreads) {
+            const float* s = C + (long)(c0 + t) * 3;
+            tile[t] = make_float4(s[0], s[1], s[2], cw[c0 + t]);
+        }
+        __syncthreads();
+        if (ok) {
+#pragma unroll 4
+            for (int t = 0; t < cnt; ++t) {
+                const float4 c = tile[t];
+                // (x2 - x1) with x2 the set2 point in every phase (approxmatch.cu:85,131,185)
+                const float d = kRowsL ? hp::sqdist(c.x - rx, c.y - ry, c.z - rz) : hp::sqdist(rx - c.x, ry - c.y, rz - c.z);
+                const float e = __builtin_amdgcn_exp2f(l2e * d);
+                if (PHASE == 3) {
+                    const float w = (e * rl) * c.w;
+                    float* mp = mcol + (long)(c0 + t) * n;
+                    *mp = first ? w : *mp + w;        // level 0 writes (the reference's zero fill + first `+=`)
+                    sum += w;
+                } else {
+                    sum += e * c.w;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!ok) return;
+    if (PHASE == 1) {
+        ratioL[row] = remL[row] / sum;
+    } else if (PHASE == 2) {
+        const float rr = remR[row];
+        const float sumr = sum * rr;
+        const float consumption = fminf(rr / (sumr + 1e-9f), 1.0f);
+        ratioR[row] = consumption * rr;
+        remR[row] = fmaxf(0.0f, rr - sumr);
+    } else {
+        remL[row] = fmaxf(0.0f, remL[row] - sum);
+    }
+}
+
 }  // namespace
 
-// floats of scratch hp_approxmatch / hp_emd_forward need besides `temp` (packed candidate records)
+// ---- tuning hook (no counterpart in the reference) -------------------------------------------------
+// Rows per lane of the three sweep families: rows1 (phase 3 + phase 1 kernel) in {0,1,2,4}, rows2 (phase 2) in
+// {0,1,2,4}, grad2 (final cost/gradient sweep) in {0,1,2}; 0 = the size heuristic.  Process-wide; every instance
+// evaluates each row with the same operations in the same order, so results do not depend on the setting.
+HP_API int hp_emd_set_rows_per_lane(int rows1, int rows2, int grad2) {
+    auto okv = [](int v, bool four) { return v == 0 || v == 1 || v == 2 || (four && v == 4); };
+    HP_CHECK_ARG(okv(rows1, true) && okv(rows2, true) && okv(grad2, false));
+    g_rows1.store(rows1);
+    g_rows2.store(rows2);
+    g_grad2.store(grad2);
+    return 0;
+}
+
+// replaces approxmatch(...)  structural_loss.cpp:11 / approxmatch.cu:330-338 — the reference's exact argument list:
+// match (b,m,n) and temp (b,2(n+m)) are the only buffers.  temp ends as cloud i's [remainL | remainR | ratioL | ratioR].
+HP_API int hp_approxmatch(int b, int n, int m, const float* xyz1, const float* xyz2, float* match, float* temp, hipStream_t stream) {
+    HP_CHECK_ARG(b >= 0 && n > 0 && m > 0);
+    if (b == 0) return 0;
+    HP_CHECK_ARG(xyz1 && xyz2 && match && temp && b <= 65535);
+    float multiL, multiR;
+    if (n >= m) {
+        multiL = 1;
+        multiR = (float)(n / m);  // integer division (approxmatch.cu:37-43)
+    } else {
+        multiL = (float)(m / n);
+        multiR = 1;
+    }
+    const dim3 blk(kThreads), gL((n + kThreads - 1) / kThreads, b), gR((m + kThreads - 1) / kThreads, b);
+    hipLaunchKernelGGL(emd_plain_init_kernel, dim3((n + m + kThreads - 1) / kThreads, b), blk, 0, stream, n, m, temp, multiL, multiR);
+    for (int lev = 0; lev < kLevels; ++lev) {
+        const float l2e = level_l2e(lev);
+        hipLaunchKernelGGL(emd_plain_kernel<1>, gL, blk, 0, stream, n, m, xyz1, xyz2, temp, match, l2e, 0);
+        hipLaunchKernelGGL(emd_plain_kernel<2>, gR, blk, 0, stream, n, m, xyz1, xyz2, temp, match, l2e, 0);
+        hipLaunchKernelGGL(emd_plain_kernel<3>, gL, blk, 0, stream, n, m, xyz1, xyz2, temp, match, l2e, lev == 0);
+    }
+    HP_RETURN_LAST_ERROR();
+}
+
+// floats of scratch hp_approxmatch_ws / hp_emd_forward need besides `temp` (packed candidate records)
 HP_API long hp_approxmatch_workspace_floats(int b, int n, int m) { return (long)b * ws_layout(n, m).per_cloud; }
 
-// replaces approxmatch(...)  structural_loss.cpp:11 / approxmatch.cu:330-338.
-// match (b,m,n) and temp (b,2(n+m)) as in the reference; `ws` is extra scratch (see header).
-HP_API int hp_approxmatch(int b, int n, int m, const float* xyz1, const float* xyz2, float* match, float* temp, float* ws,
-                          hipStream_t stream) {
+// The same result through the packed-record sweeps (the fast path): `ws` is scratch of
+// hp_approxmatch_workspace_floats floats; `match` is written once instead of read-modify-written nine times.
+HP_API int hp_approxmatch_ws(int b, int n, int m, const float* xyz1, const float* xyz2, float* match, float* temp, float* ws,
+                             hipStream_t stream) {
     HP_CHECK_ARG(b >= 0 && n > 0 && m > 0);
     if (b == 0) return 0;
     HP_CHECK_ARG(xyz1 && xyz2 && match && temp && ws && b <= 65535);
@@ -684,7 +815,7 @@ HP_API int hp_emd_forward(int b, int n, int m, const float* xyz1, const float* x
     if (rc) return rc;
     const int nb = (n + kRowsPerWg - 1) / kRowsPerWg, mb = (m + kRowsPerWg - 1) / kRowsPerWg;
     if (grad2) {
-        static const int genv = getenv("HP_EMD_GRAD2_R") ? atoi(getenv("HP_EMD_GRAD2_R")) : 0;
+        const int genv = g_grad2.load(std::memory_order_relaxed);
         const int mbr = (m + 2 * kRowsPerWg - 1) / (2 * kRowsPerWg);
         // two rows per lane when that still leaves >= 2 waves per SIMD (as in run_levels; -0.01 ms at B=64, N=2048)
         const int gr = genv ? genv : ((long)b * mbr * (kThreads / 64) >= 2048 ? 2 : 1);

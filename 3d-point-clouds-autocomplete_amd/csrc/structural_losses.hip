@@ -14,7 +14,8 @@
 //  * the approximate matching itself (approxmatch.cu:34-213) is in emd.hip; here: the two kernels that
 //    consume a materialised `match` (MatchCost / MatchCostGrad API parity).
 //  * all reductions are ordered or exact: no float atomics anywhere — the scatter half of nndistancegrad (global
-//    float atomicAdd in the reference, nndistance.cu:146-151) accumulates in LDS in 64-bit fixed point.
+//    float atomicAdd in the reference, nndistance.cu:146-151) accumulates in LDS in 64-bit fixed point on a
+//    data-scaled grid.
 #include "hp_common.h"
 #include <algorithm>
 
@@ -113,8 +114,12 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 // The reference scatters with global float atomicAdd (nndistance.cu:149-151).  Early in training most of a cloud
 // picks the same few neighbours, which serialises those atomics on a handful of addresses (130 us at B=64, N=2048).
 // Here a workgroup owns a tile of 2048 targets of one cloud and accumulates the scatter half in LDS, in 64-bit
-// fixed point (2^-32 steps, |sum| < 2^31): integer addition is associative, so the result does not depend on the
-// order the sources arrive in — run-to-run identical, unlike the reference — and contention stays inside the CU.
+// fixed point: integer addition is associative, so the result does not depend on the order the sources arrive in —
+// run-to-run identical, unlike the reference — and contention stays inside the CU.  The grid step is chosen per
+// workgroup from the data: a first pass over the tile's sources finds the largest term, and the step 2^-shift is the
+// finest for which n such terms cannot overflow 62 bits — every fp32 term is then represented to >= 2^-50 of the
+// largest one (far below an fp32 ulp of the sum) whatever the magnitude of the upstream gradients (1e-6 for a
+// mean-reduced caller, 0.05 in training); the maximum is order-independent, so the result stays deterministic.
 // Every output element is written exactly once (no memset, nndistance.cu:156-157).
 constexpr int kGradTile = 2048;
 struct GradSide {
@@ -128,29 +133,46 @@ struct GradSide {
     int m, n, g_t_stride, g_s_stride;
 };
 
-__device__ __forceinline__ unsigned long long to_fixed(float x) {
-    const float y = fminf(fmaxf(x * 4294967296.f, -4.6e18f), 4.6e18f);
-    return (unsigned long long)__float2ll_rn(y);
+__device__ __forceinline__ unsigned long long to_fixed(float x, double scale) {
+    return (unsigned long long)__double2ll_rn((double)x * scale);   // power-of-two scale: the product is exact
 }
 
 __global__ __launch_bounds__(kThreads) void nn_grad_side_kernel(const GradSide a) {
     __shared__ unsigned long long acc[kGradTile * 3];
+    __shared__ float wmax[kThreads / 64];
     const int cloud = blockIdx.y, tid = threadIdx.x;
     const int j0 = blockIdx.x * kGradTile, cnt = min(kGradTile, a.m - j0);
     for (int u = tid; u < cnt * 3; u += kThreads) acc[u] = 0ull;
-    __syncthreads();
     const float* S = a.s + (size_t)cloud * a.n * 3;
     const float* T = a.t + (size_t)cloud * a.m * 3;
     const int* is = a.idx_s + (size_t)cloud * a.n;
+    float mx = 0.f;
     for (int i = tid; i < a.n; i += kThreads) {
         const int j = is[i] - j0;
         if ((unsigned)j < (unsigned)cnt) {
             const float g = a.g_s[((size_t)cloud * a.n + i) * a.g_s_stride] * 2;
             const float* p = S + (size_t)i * 3;
             const float* q = T + (size_t)(j0 + j) * 3;
-            atomicAdd(&acc[j * 3 + 0], to_fixed(-(g * (p[0] - q[0]))));
-            atomicAdd(&acc[j * 3 + 1], to_fixed(-(g * (p[1] - q[1]))));
-            atomicAdd(&acc[j * 3 + 2], to_fixed(-(g * (p[2] - q[2]))));
+            mx = fmaxf(mx, fmaxf(fabsf(g * (p[0] - q[0])), fmaxf(fabsf(g * (p[1] - q[1])), fabsf(g * (p[2] - q[2])))));
+        }
+    }
+    mx = hp::wave_max(mx);
+    if ((tid & 63) == 0) wmax[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    int ex = 0;
+    if (mx > 0.f && mx < 3.0e38f) (void)frexpf(mx, &ex);                     // mx < 2^ex
+    const int shift = min(max(61 - ex - (32 - __clz(a.n)), -64), 300);       // n terms < 2^(32 - clz(n))
+    const double scale = ldexp(1.0, shift), inv_scale = ldexp(1.0, -shift);
+    for (int i = tid; i < a.n; i += kThreads) {
+        const int j = is[i] - j0;
+        if ((unsigned)j < (unsigned)cnt) {
+            const float g = a.g_s[((size_t)cloud * a.n + i) * a.g_s_stride] * 2;
+            const float* p = S + (size_t)i * 3;
+            const float* q = T + (size_t)(j0 + j) * 3;
+            atomicAdd(&acc[j * 3 + 0], to_fixed(-(g * (p[0] - q[0])), scale));
+            atomicAdd(&acc[j * 3 + 1], to_fixed(-(g * (p[1] - q[1])), scale));
+            atomicAdd(&acc[j * 3 + 2], to_fixed(-(g * (p[2] - q[2])), scale));
         }
     }
     __syncthreads();
@@ -162,7 +184,7 @@ __global__ __launch_bounds__(kThreads) void nn_grad_side_kernel(const GradSide a
         const float* q = S + (size_t)it[j0 + j] * 3;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float sc = (float)((double)(long long)acc[j * 3 + c] * (1.0 / 4294967296.0));
+            const float sc = (float)((double)(long long)acc[j * 3 + c] * inv_scale);
             a.out[gj * 3 + c] = g * (p[c] - q[c]) + sc;
         }
     }
@@ -225,6 +247,34 @@ __global__ __launch_bounds__(256) void matchcost_finish_kernel(const float* __re
     for (int i = threadIdx.x; i < per_cloud; i += 256) s += (double)p[i];
     const double t = hp::block_sum(s, red);
     if (threadIdx.x == 0) out[blockIdx.x] = (float)t;
+}
+
+// scratch-free cost: one workgroup per cloud (see hp_matchcost)
+constexpr int kCloudThreads = 1024;
+__global__ __launch_bounds__(kCloudThreads) void matchcost_cloud_kernel(int n, int m, const float* __restrict__ xyz1,
+                                                                        const float* __restrict__ xyz2, const float* __restrict__ match,
+                                                                        float* __restrict__ out) {
+    __shared__ double red[kCloudThreads / 64];
+    const int cloud = blockIdx.x, tid = threadIdx.x;
+    const float* P = xyz1 + (size_t)cloud * n * 3;
+    const float* Q = xyz2 + (size_t)cloud * m * 3;
+    const float* M = match + (size_t)cloud * m * n;
+    double total = 0;
+    for (int j0 = 0; j0 < n; j0 += kCloudThreads) {
+        const int j = j0 + tid;
+        if (j < n) {
+            const float px = P[j * 3], py = P[j * 3 + 1], pz = P[j * 3 + 2];
+            float acc = 0.f;
+#pragma unroll 4
+            for (int l = 0; l < m; ++l) {   // Q[l] is wave-uniform: scalar loads
+                const float d = __builtin_sqrtf(hp::sqdist(Q[l * 3] - px, Q[l * 3 + 1] - py, Q[l * 3 + 2] - pz));
+                acc = __builtin_fmaf(M[(size_t)l * n + j], d, acc);
+            }
+            total += (double)acc;
+        }
+    }
+    const double t = hp::block_sum(total, red);
+    if (tid == 0) out[cloud] = (float)t;
 }
 
 // grad1[l] = sum_k match[k*n+l] * (p_l - q_k) / max(|p_l - q_k|, 1e-10)   (approxmatch.cu:301-322)
@@ -380,11 +430,24 @@ HP_API long hp_matchcost_workspace_floats(int b, int n, int m) {
     return (long)b * ((n + kThreads - 1) / kThreads) * ((m + kLT - 1) / kLT);
 }
 
-// replaces matchcost(...)  structural_loss.cpp:12 / approxmatch.cu:340-347
+// replaces matchcost(...)  structural_loss.cpp:12 / approxmatch.cu:340-347 — the reference's exact argument list (no
+// scratch): one 1024-thread workgroup per cloud streams that cloud's match block (the reference: 32 blocks of 512 in
+// all), thread sums in fp32 like the reference's (:232-243), the block tree (:244-252) as an ordered fp64 sum.
+// Callers that can allocate hp_matchcost_workspace_floats floats get the chip-wide two-stage sum: hp_matchcost_ws.
 HP_API int hp_matchcost(int b, int n, int m, const float* xyz1, const float* xyz2, const float* match, float* out,
-                        float* partials, hipStream_t stream) {
+                        hipStream_t stream) {
     HP_CHECK_ARG(b >= 0 && n > 0 && m > 0);
     if (b == 0) return 0;
+    HP_CHECK_ARG(xyz1 && xyz2 && match && out);
+    hipLaunchKernelGGL(matchcost_cloud_kernel, dim3(b), dim3(kCloudThreads), 0, stream, n, m, xyz1, xyz2, match, out);
+    HP_RETURN_LAST_ERROR();
+}
+
+HP_API int hp_matchcost_ws(int b, int n, int m, const float* xyz1, const float* xyz2, const float* match, float* out,
+                           float* partials, hipStream_t stream) {
+    HP_CHECK_ARG(b >= 0 && n > 0 && m > 0);
+    if (b == 0) return 0;
+    HP_CHECK_ARG(b <= 65535 && partials);
     dim3 grid((n + kThreads - 1) / kThreads, (m + kLT - 1) / kLT, b);
     hipLaunchKernelGGL(matchcost_kernel, grid, dim3(kThreads), 0, stream, n, m, xyz1, xyz2, match, partials);
     hipLaunchKernelGGL(matchcost_finish_kernel, dim3(b), dim3(256), 0, stream, partials, (int)(grid.x * grid.y), out);

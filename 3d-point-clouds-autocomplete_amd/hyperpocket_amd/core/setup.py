@@ -1,4 +1,4 @@
-"""The three helpers of core/setup.py the training step depends on; the rest of that
+"""The two helpers of core/setup.py the training step depends on; the rest of that
 file (result dirs, logging, checkpoint restore) is control plane and out of scope."""
 import random
 
@@ -12,13 +12,6 @@ def seed_setup(seed: int = 0):
     np.random.seed(seed)
     torch.manual_seed(seed)
     torch.cuda.manual_seed_all(seed)
-
-
-def cuda_setup(gpu_idx=0):
-    """core/setup.py:57-60"""
-    device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
-    torch.cuda.set_device(gpu_idx)
-    return device
 
 
 def weights_init(m):

@@ -1,7 +1,10 @@
 """Drop-in for the reference's compiled module ``StructuralLossesBackend``
 (utils/pytorch_structural_losses/structural_loss.cpp:130-136): the same five functions with the
 same argument order, output shapes/dtypes and `b, n` taken from ``set_d``, `m` from ``set_q``
-(SURVEY Q12 — no silent broadcasting), bound to the HIP C ABI instead of the CUDA launchers.
+(SURVEY Q12 — no silent broadcasting), bound to the HIP C ABI instead of the CUDA launchers.  A binding may allocate, so ApproxMatch / MatchCost call the
+scratch-taking fast variants (hp_approxmatch_ws / hp_matchcost_ws); the launchers with the reference's exact argument
+lists (hp_approxmatch / hp_matchcost, structural_loss.cpp:11-12) are what INTEGRATION.md §2 rebinds and what
+tests/test_structural_losses_gpu.py calls through ctypes.
 """
 import torch
 
@@ -21,7 +24,7 @@ def ApproxMatch(set_d, set_q):
     temp = torch.empty((b, (n + m) * 2), dtype=torch.float32, device=set_d.device)
     ws = torch.empty((max(1, load_library().hp_approxmatch_workspace_floats(b, n, m)),), dtype=torch.float32,
                      device=set_d.device)
-    call("hp_approxmatch", b, n, m, set_d, set_q, match, temp, ws, current_stream(set_d.device))
+    call("hp_approxmatch_ws", b, n, m, set_d, set_q, match, temp, ws, current_stream(set_d.device))
     return [match, temp]
 
 
@@ -34,7 +37,7 @@ def MatchCost(set_d, set_q, match):
     out = torch.empty((b,), dtype=torch.float32, device=set_d.device)
     part = torch.empty((max(1, load_library().hp_matchcost_workspace_floats(b, n, m)),), dtype=torch.float32,
                        device=set_d.device)
-    call("hp_matchcost", b, n, m, set_d, set_q, match, out, part, current_stream(set_d.device))
+    call("hp_matchcost_ws", b, n, m, set_d, set_q, match, out, part, current_stream(set_d.device))
     return out
 
 

@@ -2,6 +2,10 @@
 """bench.py — HyperPocket training-step throughput on MI355X (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-emd] [--no-cpu-baseline]
+    python bench.py --workload chamfer-stress [--gpus N]      # BASELINE.json configs[4]: B=64/GPU, N=8192 Chamfer fwd+bwd
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (one process per GPU through
+`python -m torch.distributed.run`, before this process has touched the GPU); under torchrun it is a rank.
 
 A "step" is one full training step of the hot path on one batch of synthetic clouds resident in
 HBM: forward (2 encoders -> hypernetwork -> batched target networks on freshly sampled points)
@@ -12,6 +16,7 @@ value = clouds/s over all ranks (weak scaling: B per GPU fixed).
 
 One JSON line on rank 0; besides the contract keys it carries
   roofline      the dominant kernel (fp32 MFMA GEMM of the encoder stack), timed live with HIP events
+  roofline_emd  the EMD sweep family (45 % of the step): VALU issue cycles of the compiled loops / measured time
   cpu_baseline  the oracle's torch-CPU restatement of the reference step timed on this box's cores
   breakdown     extra figures (Chamfer-only step, per-op times) — informational
 """
@@ -20,6 +25,8 @@ import copy
 import gc
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -45,7 +52,9 @@ MODEL_CFG = {
     "target_network_input": {"constant": False, "normalization": {"enable": True, "type": "progressive", "epoch": 100}},
 }
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+PEAK_F32_VALU_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector peak (64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak
+PEAK_VALU_ISSUE_TCYC = 1024 * 2.4e9 / 1e12   # SIMD issue cycles per second: 256 CUs x 4 SIMDs x 2.4 GHz (same guide)
 
 
 def synth_batch(b, n_half, device, seed):
@@ -139,13 +148,183 @@ def cpu_baseline(n_half, emd_coef, sample_b=4, timed_steps=2):
                       f"existing/missing ({sample_b},{n_half},3), gt ({sample_b},{2 * n_half},3); {dt:.2f} s/step"}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside torchrun: start N fresh ranks (one process per GPU) and relay their output.
+    Nothing in this process has initialised HIP yet (importing torch does not), and it never does: the children are
+    separate Python processes started through torch.distributed.run, no exec of a GPU-holding process."""
+    if not os.environ.get("HP_BENCH_ONE_DEVICE") and os.environ.get("HP_BENCH_BACKEND", "nccl") == "nccl" \
+            and "--rendezvous-only" not in sys.argv:
+        have = torch.cuda.device_count()          # counts devices without creating a HIP context
+        if have < n:
+            print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def rendezvous_only(args, world, rank):
+    """Launcher self-test (`--rendezvous-only`, used by the CPU suite): the ranks form the group, run one all-reduce and a
+    barrier, rank 0 prints a line with the contract's rank bookkeeping.  gloo when no GPU is present."""
+    backend = os.environ.get("HP_BENCH_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        dev = "cuda" if backend == "nccl" else "cpu"
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        t = torch.ones(4, device=dev) * (rank + 1)
+        dist.all_reduce(t)
+        dist.barrier()
+        total, ranks = float(t[0]), dist.get_world_size()
+        dist.destroy_process_group()
+    else:
+        total, ranks = 1.0, 1
+    if rank == 0:
+        print(json.dumps({"rendezvous_only": True, "n_gpus": world, "rccl_ranks": ranks, "gpus_arg": args.gpus,
+                          "backend": backend if world > 1 else None, "allreduce_sum": total}), flush=True)
+    if os.environ.get("HP_BENCH_FAIL_RANK") == str(rank):      # test hook: a failing child must fail the launcher
+        sys.exit(3)
+
+
+def _pmc_profile(name):
+    path = os.path.join(ROOT, "profiles", name)
+    return json.load(open(path)) if os.path.exists(path) else None
+
+
+def roofline_emd(batch, n):
+    """The EMD sweep family (emd_rows1/rows2/grad2: the largest time block of the Chamfer+EMD step) against its own bound.
+    It is neither HBM- nor MFMA-bound (scalar-path candidates, 440-810 GB/s, no matrix work): it is bound by VALU ISSUE —
+    each (row, candidate-pair) costs a fixed instruction sequence, quarter-rate v_exp_f32 included.  Model: per kernel,
+    the VALU instructions of the compiled inner loop priced at MI355X_MICROARCH.md's issue costs (transcendental 8,
+    every other vector op 4 cycles per wave-instruction) x the wave-instructions one hp_emd_forward call executes
+    (profiles/r02_emd_issue_model.json, produced by tools/emd_issue_model.py from the shipped code object's ISA).
+    achieved = those useful issue cycles / the call's duration measured live with HIP events; peak = issue cycles the
+    chip has (1024 SIMDs x 2.4 GHz)."""
+    from hyperpocket_amd._lib import call, current_stream, load_library
+    import ctypes
+    model = _pmc_profile("r02_emd_issue_model.json")
+    lib = load_library()
+    lib.hp_emd_partials_floats.restype = ctypes.c_long
+    f32 = dict(dtype=torch.float32, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(7)
+    a = torch.rand(batch, n, 3, generator=g, **f32) - 0.5
+    c = torch.rand(batch, n, 3, generator=g, **f32) - 0.5
+    temp = torch.empty((batch, 4 * n), **f32)
+    ws = torch.empty((lib.hp_approxmatch_workspace_floats(batch, n, n),), **f32)
+    part = torch.empty((lib.hp_emd_partials_floats(batch, n, n),), **f32)
+    cost = torch.empty((batch,), **f32)
+    g2 = torch.empty((batch, n, 3), **f32)
+    st = current_stream(a.device)
+    ms = event_time_ms(lambda: call("hp_emd_forward", batch, n, n, a, c, temp, ws, part, cost, None, g2, st), iters=20, warm=10)
+    out = {"bound": "valu-issue", "kernel": "hp_emd_forward = emd_rows1_kernel x10 + emd_rows2_kernel x9 + emd_grad2_kernel "
+           f"(B={batch}, n=m={n}, grad2 + cost)", "avg_call_ms": round(ms, 4), "peak": round(PEAK_VALU_ISSUE_TCYC, 4),
+           "unit": "T issue-cycles/s", "exp_per_call": 37.0 * batch * n * n}
+    if model and model.get("batch") == batch and model.get("n") == n:
+        cyc = model["issue_cycles_per_call"]
+        out.update({"achieved": round(cyc / (ms * 1e-3) / 1e12, 4), "frac": round(cyc / (ms * 1e-3) / 1e12 / PEAK_VALU_ISSUE_TCYC, 4),
+                    "issue_cycles_per_call": cyc, "model": "profiles/r02_emd_issue_model.json",
+                    "traffic": model.get("hbm_bytes_per_call")})
+    else:
+        out.update({"achieved": None, "frac": None, "traffic": None})
+    return out
+
+
+def chamfer_stress(args, world, rank, local_rank, grouped, device):
+    """BASELINE.json configs[4]: synthetic random clouds, B=64 per GPU, N=8192, fp32 — the O(N^2) Chamfer forward
+    (both directed nearest-neighbour passes + the batch sum) and backward (gradients of both sets), nothing else.
+    A "step" = one forward + backward over the resident batch; value = point-pair distance evaluations per second
+    (2 directions x B x N x N per step) over all ranks.  The kernel is fp32-VALU-bound (820 FLOP per HBM byte):
+    `roofline` prices it against the vector peak with the 8 FLOP per pair of SURVEY §8d, and reports the HBM side next
+    to it (algorithmic bytes / time, and the PMC-measured bytes when profiles/ holds them for this shape)."""
+    import ctypes
+    from hyperpocket_amd._lib import call, current_stream, load_library
+    lib = load_library()
+    B, N = args.batch, args.points
+    f32 = dict(dtype=torch.float32, device=device)
+    g = torch.Generator(device=device).manual_seed(2020 + rank)
+    x = torch.rand(B, N, 3, generator=g, **f32) - 0.5
+    y = torch.rand(B, N, 3, generator=g, **f32) - 0.5
+    d1, d2 = torch.empty((B, N), **f32), torch.empty((B, N), **f32)
+    i1 = torch.empty((B, N), dtype=torch.int32, device=device)
+    i2 = torch.empty((B, N), dtype=torch.int32, device=device)
+    part = torch.empty((lib.hp_chamfer_workspace_floats(B, N, N),), **f32)
+    loss = torch.empty((), **f32)
+    one = torch.ones((), **f32)
+    gx, gy = torch.empty_like(x), torch.empty_like(y)
+    st = current_stream(device)
+
+    def fwd():
+        call("hp_chamfer_forward", B, N, x, N, y, d1, i1, d2, i2, part, loss, st)
+
+    def bwd():
+        call("hp_chamfer_backward", B, N, x, N, y, i1, i2, one, gx, gy, st)
+
+    def sync():
+        if grouped:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        fwd(); bwd()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fwd(); bwd()
+    sync()
+    dt = time.perf_counter() - t0
+    if grouped:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    ms_per_step = dt / args.steps * 1e3
+    pairs = 2.0 * B * N * N
+    if rank != 0:
+        return
+    line = {"metric": f"chamfer-stress point-pair evaluations/sec at B={B}/GPU, N={N} (Chamfer forward + backward)",
+            "value": round(pairs * world / (ms_per_step * 1e-3), 1), "unit": "pairs/s", "n_gpus": world,
+            "rccl_ranks": dist.get_world_size() if grouped else 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[4] per-GPU shape: Chamfer forward+backward on two U(-0.5,0.5) "
+                                   f"sets of ({B},{N},3), fp32; no model, no collective (clouds shard over ranks)",
+                       "global_batch": B * world, "points": N, "parallelism": f"dp{world}"},
+            "final_loss": loss.item()}
+    if not args.no_extras:
+        ms_f = event_time_ms(fwd, iters=10, warm=3)
+        ms_b = event_time_ms(bwd, iters=10, warm=3)
+        flops = 8.0 * pairs                               # SURVEY §8d: 3 sub, 3 mul, 2 add per pair; compares excluded
+        alg_bytes = B * (2 * N * 12 + 2 * N * 8)          # SURVEY §8d: (n+m)*12 B read + (n+m)*8 B written per cloud
+        tf = flops / (ms_f * 1e-3) / 1e12
+        pmc = _pmc_profile("r02_pmc_chamfer_n8192.json")
+        traffic = pmc["hbm_bytes_per_launch"] if pmc and pmc.get("batch") == B and pmc.get("n") == N else None
+        line["roofline"] = {"bound": "valu", "kernel": "nn_distance_kernel (both directed passes of the Chamfer forward, one launch)",
+                            "achieved": round(tf, 2), "peak": PEAK_F32_VALU_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(tf / PEAK_F32_VALU_TFLOPS, 4), "traffic": traffic,
+                            "avg_launch_ms": round(ms_f, 4), "flops_per_launch": flops,
+                            "algorithmic_bytes_per_launch": alg_bytes,
+                            "hbm_GBps_algorithmic": round(alg_bytes / (ms_f * 1e-3) / 1e9, 2),
+                            "hbm_frac_of_peak": round(alg_bytes / (ms_f * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
+                            "backward_avg_ms": round(ms_b, 4)}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="clouds per GPU")
-    ap.add_argument("--points", type=int, default=2048, help="points per ground-truth cloud")
+    ap.add_argument("--points", type=int, default=None, help="points per cloud (default 2048; chamfer-stress: 8192)")
+    ap.add_argument("--workload", choices=["train-step", "chamfer-stress"], default="train-step")
+    ap.add_argument("--rendezvous-only", action="store_true", help="launcher self-test: form the group, one all-reduce, exit")
     ap.add_argument("--no-emd", action="store_true", help="reference-faithful Chamfer-only loss as the headline step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline/breakdown side measurements")
@@ -153,6 +332,13 @@ def main():
                     help="run only the roofline leg (the dominant kernel at the step's shape) and print its object: the "
                          "command profiles/ pairs with `rocprofv3 --kernel-trace --stats`")
     args = ap.parse_args()
+    if args.points is None:
+        args.points = 8192 if args.workload == "chamfer-stress" else 2048
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))       # before anything here touches the GPU
+    if args.rendezvous_only:
+        rendezvous_only(args, int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")))
+        return
     if args.roofline_only:
         torch.cuda.set_device(0)
         print(json.dumps({"roofline": roofline_dominant_kernel(args.batch, args.points // 2)}), flush=True)
@@ -189,10 +375,16 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}: reporting n_gpus={world}", file=sys.stderr)
     device = torch.device("cuda", local_rank if world > 1 else 0)
     grouped = world > 1 or force_exchange
+    if args.workload == "chamfer-stress":
+        chamfer_stress(args, world, rank, local_rank, grouped, device)
+        if grouped:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from hyperpocket_amd.core.engine import TrainEngine
     from hyperpocket_amd.core.setup import weights_init
@@ -239,7 +431,8 @@ def main():
         line = {
             "metric": "train-step point-clouds/sec at B=64, N=2048 (Chamfer+EMD)" if not args.no_emd
             else "train-step point-clouds/sec at B=64, N=2048 (Chamfer only)",
-            "value": round(value, 2), "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 2), "unit": "clouds/s", "n_gpus": world,
+            "rccl_ranks": dist.get_world_size() if grouped else 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"HyperPocket 128+128 train step, B={args.batch}/GPU, existing/missing (B,{n_half},3), "
@@ -251,6 +444,8 @@ def main():
         }
         if not args.no_extras:
             line["roofline"] = roofline_dominant_kernel(args.batch, n_half)
+            if emd_coef:
+                line["roofline_emd"] = roofline_emd(args.batch, args.points)
             if world == 1:
                 # informational: the reference-faithful Chamfer-only step on the same inputs
                 from hyperpocket_amd import ops

@@ -38,30 +38,43 @@ int hp_nndistancegrad(int b, int n, const float* xyz1, int m, const float* xyz2,
                       const int* idx1, const float* grad_dist2, const int* idx2, float* grad_xyz1, float* grad_xyz2,
                       hpStream_t stream);
 
-/* approxmatch  (structural_loss.cpp:11, approxmatch.cu:330-338)
- * match (b, m, n), temp (b, 2*(n+m)) as in the reference.  One extra argument: `ws`, scratch of
- * hp_approxmatch_workspace_floats(b,n,m) floats (packed candidate records incl. the per-level scaling
- * vectors; lets `match` be written once instead of read-modify-written nine times). */
-long hp_approxmatch_workspace_floats(int b, int n, int m);
-int hp_approxmatch(int b, int n, int m, const float* xyz1, const float* xyz2, float* match, float* temp, float* ws,
+/* approxmatch  (structural_loss.cpp:11, approxmatch.cu:330-338) — the reference's exact argument list.
+ * match (b, m, n), temp (b, 2*(n+m)) as in the reference; no other buffer.  Keeps the reference's data flow (the
+ * four vectors of temp are the only state, match is read-modify-written once per level) on a chip-wide grid. */
+int hp_approxmatch(int b, int n, int m, const float* xyz1, const float* xyz2, float* match, float* temp,
                    hpStream_t stream);
+/* The same result ~2.5x faster for a caller that can allocate: `ws` = scratch of
+ * hp_approxmatch_workspace_floats(b,n,m) floats (packed candidate records incl. the per-level scaling vectors; lets
+ * `match` be written once instead of read-modify-written nine times).  What this repo's Python binding calls. */
+long hp_approxmatch_workspace_floats(int b, int n, int m);
+int hp_approxmatch_ws(int b, int n, int m, const float* xyz1, const float* xyz2, float* match, float* temp, float* ws,
+                      hpStream_t stream);
+/* Tuning hook (no counterpart in the reference): rows per lane of the packed-record sweeps — rows1 (phase 3 + phase 1
+ * kernel) and rows2 (phase 2) in {0,1,2,4}, grad2 (final cost/gradient sweep) in {0,1,2}; 0 = the size heuristic.
+ * Process-wide.  Every setting evaluates each row with the same operations in the same order (results identical bit
+ * for bit; tests/test_structural_losses_gpu.py). */
+int hp_emd_set_rows_per_lane(int rows1, int rows2, int grad2);
 
 /* Match-free EMD (what match_cost.py:9-46 computes through ApproxMatch + MatchCost + MatchCostGrad, without ever
  * writing the (b,m,n) match tensor): cost (b,) plus whichever of grad1 = d cost/d xyz1, grad2 = d cost/d xyz2 the
  * caller asks for (the cost rides on one of those sweeps); hp_emd_backward computes grad2 later from the packed
  * records hp_emd_forward left in `ws` (hp_approxmatch_workspace_floats).
- * partials: hp_emd_partials_floats floats.  temp as in hp_approxmatch. */
+ * partials: hp_emd_partials_floats floats.  temp as in hp_approxmatch; ws as in hp_approxmatch_ws. */
 long hp_emd_partials_floats(int b, int n, int m);
 int hp_emd_forward(int b, int n, int m, const float* xyz1, const float* xyz2, float* temp, float* ws, float* partials,
                    float* cost, float* grad1 /* or NULL */, float* grad2 /* or NULL */, hpStream_t stream);
 int hp_emd_backward(int b, int n, int m, const float* xyz1, const float* xyz2, const float* ws, float* grad2,
                     hpStream_t stream);
 
-/* matchcost  (structural_loss.cpp:12, approxmatch.cu:340-347); `partials`: scratch of
- * hp_matchcost_workspace_floats floats (ordered two-stage sum instead of one block per cloud). */
-long hp_matchcost_workspace_floats(int b, int n, int m);
+/* matchcost  (structural_loss.cpp:12, approxmatch.cu:340-347) — the reference's exact argument list: one
+ * 1024-thread workgroup per cloud, ordered sums, no scratch. */
 int hp_matchcost(int b, int n, int m, const float* xyz1, const float* xyz2, const float* match, float* out,
-                 float* partials, hpStream_t stream);
+                 hpStream_t stream);
+/* The same sum chip-wide in two ordered stages for a caller that can allocate `partials`
+ * (hp_matchcost_workspace_floats floats): 5.9 TB/s at B=64, N=2048 instead of one workgroup per cloud. */
+long hp_matchcost_workspace_floats(int b, int n, int m);
+int hp_matchcost_ws(int b, int n, int m, const float* xyz1, const float* xyz2, const float* match, float* out,
+                    float* partials, hpStream_t stream);
 
 /* matchcostgrad  (structural_loss.cpp:13, approxmatch.cu:349-357) */
 int hp_matchcostgrad(int b, int n, int m, const float* xyz1, const float* xyz2, const float* match, float* grad1,

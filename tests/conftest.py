@@ -6,7 +6,6 @@ package (3d-point-clouds-autocomplete_amd/).
 """
 import ctypes
 import os
-import os
 import subprocess
 import sys
 
@@ -63,13 +62,24 @@ class OracleLib:
                                     self._p(gd2), self._p(i2), self._p(g1), self._p(g2))
         return g1, g2
 
-    def approxmatch(self, xyz1, xyz2):
+    def approxmatch(self, xyz1, xyz2, contract=0):
+        """contract: which fma contractions of the reference source to assume (oracle/structural_losses_ref.c);
+        0 = the restatement proper."""
         xyz1, xyz2 = np.ascontiguousarray(xyz1, np.float32), np.ascontiguousarray(xyz2, np.float32)
         b, n, m = xyz1.shape[0], xyz1.shape[1], xyz2.shape[1]
         match = np.empty((b, m, n), np.float32)
         temp = np.empty((b, 2 * (n + m)), np.float32)
-        self.lib.ref_approxmatch(b, n, m, self._p(xyz1), self._p(xyz2), self._p(match), self._p(temp))
+        self.lib.ref_approxmatch_ex(b, n, m, self._p(xyz1), self._p(xyz2), self._p(match), self._p(temp), int(contract))
         return match, temp
+
+    def approxmatch_f64(self, xyz1, xyz2):
+        """The nine-level algorithm in fp64 with libm exp: (match (b,m,n) float64, cost (b,) float64)."""
+        xyz1, xyz2 = np.ascontiguousarray(xyz1, np.float32), np.ascontiguousarray(xyz2, np.float32)
+        b, n, m = xyz1.shape[0], xyz1.shape[1], xyz2.shape[1]
+        match = np.empty((b, m, n), np.float64)
+        cost = np.empty((b,), np.float64)
+        self.lib.ref_approxmatch_f64(b, n, m, self._p(xyz1), self._p(xyz2), self._p(match), self._p(cost))
+        return match, cost
 
     def matchcost(self, xyz1, xyz2, match):
         xyz1, xyz2 = np.ascontiguousarray(xyz1, np.float32), np.ascontiguousarray(xyz2, np.float32)

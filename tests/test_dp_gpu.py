@@ -143,3 +143,38 @@ def test_bench_runs_every_collective_in_a_one_rank_rccl_group():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["final_loss"] == line["final_loss"]
+
+
+def _bench(args, extra_env, timeout=900):
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **extra_env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_starts_two_ranks_itself():
+    """`python bench.py --gpus 2` with no torchrun around it: bench.py spawns the two ranks (before touching the GPU) and
+    rank 0 prints ONE line with n_gpus = 2.  One GPU here, so both ranks sit on cuda:0 and talk over gloo (the test hooks
+    HP_BENCH_BACKEND / HP_BENCH_ONE_DEVICE); on a multi-GPU node the same command line runs one rank per GPU over RCCL."""
+    line = _bench(["--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "8", "--no-extras", "--no-cpu-baseline"],
+                  {"HP_BENCH_BACKEND": "gloo", "HP_BENCH_ONE_DEVICE": "1"})
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2
+    assert line["config"]["global_batch"] == 16 and line["value"] > 0 and line["final_loss"] == line["final_loss"]
+
+
+def test_bench_chamfer_stress_workload_line():
+    """BASELINE.json configs[4] at a reduced batch (the bench default is B=64/GPU, N=8192): one line with pairs/s and the
+    VALU roofline object."""
+    line = _bench(["--workload", "chamfer-stress", "--batch", "4", "--steps", "3", "--warmup", "1"], {})
+    assert line["unit"] == "pairs/s" and line["config"]["points"] == 8192 and line["n_gpus"] == 1
+    assert abs(line["value"] - 2 * 4 * 8192 * 8192 / (line["ms_per_step"] * 1e-3)) <= 1e-3 * line["value"]
+    rf = line["roofline"]
+    assert rf["bound"] == "valu" and 0 < rf["frac"] < 1 and rf["flops_per_launch"] == 8.0 * 2 * 4 * 8192 * 8192

@@ -11,7 +11,9 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import golden
+import sys
+
+from conftest import ROOT, golden
 
 
 def model_config(random_out=128, real_out=128):
@@ -216,3 +218,31 @@ else:
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "REFUSED:" in out.stdout
+
+
+def _bench_launcher(env_extra, *flags):
+    import json
+    import subprocess
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], env=env, capture_output=True, text=True,
+                       timeout=600)
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    return r.returncode, lines
+
+
+def test_bench_gpus_n_spawns_n_ranks_and_reports_them():
+    """bench.py --gpus N outside torchrun starts N rank processes itself (the driver runs plain
+    `python bench.py --gpus 8`).  --rendezvous-only stops after the group's first all-reduce, so this runs without a GPU
+    (gloo); tests/test_dp_gpu.py runs the real step through the same launcher."""
+    rc, lines = _bench_launcher({}, "--gpus", "2", "--rendezvous-only")
+    assert rc == 0 and len(lines) == 1
+    assert lines[0]["n_gpus"] == 2 and lines[0]["rccl_ranks"] == 2 and lines[0]["allreduce_sum"] == 3.0
+    rc, lines = _bench_launcher({}, "--gpus", "3", "--rendezvous-only")
+    assert rc == 0 and lines[0]["n_gpus"] == 3 and lines[0]["allreduce_sum"] == 6.0
+
+
+def test_bench_launcher_fails_when_a_rank_fails():
+    rc, _ = _bench_launcher({"HP_BENCH_FAIL_RANK": "1"}, "--gpus", "2", "--rendezvous-only")
+    assert rc != 0

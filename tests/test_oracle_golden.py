@@ -189,3 +189,25 @@ def test_matchcostgrad_oracle_finite_difference(oracle_lib):
         fd = (cost(ap) - cost(am)) / (2 * h)
         assert abs(fd - g1[0, j, c]) <= 1e-3 * max(1.0, abs(fd))
     assert np.abs(g1.sum(1) + g2.sum(1)).max() < 1e-3   # translation invariance
+
+
+@pytest.mark.parametrize("b,n,m,seed", [(4, 256, 256, 1), (4, 512, 512, 2), (4, 300, 150, 4), (2, 1024, 1024, 3)])
+def test_approxmatch_oracle_distance_from_fp64_under_every_contraction(oracle_lib, b, n, m, seed):
+    """EMD parity is unpinned (no reference build / vectors), and whether nvcc contracted the reference's
+    `w=__expf(d)*buf; suml+=w` into fma is unknowable here.  What is measurable: how far the fp32
+    restatement sits from the fp64 evaluation of the same nine-level algorithm under EVERY contraction assumption
+    (oracle/structural_losses_ref.c `contract` bits).  Finding, asserted here: single match entries differ by ~1e-4
+    between any two fp32 evaluations (the auction amplifies rounding), while the cost — the scalar north_star gates at
+    1e-5 — agrees with exact arithmetic to < 1e-6 for every variant: the contraction question cannot move the gate."""
+    r = np.random.RandomState(seed)
+    a = r.rand(b, n, 3).astype(np.float32) - 0.5
+    c = r.rand(b, m, 3).astype(np.float32) - 0.5
+    m64, c64 = oracle_lib.approxmatch_f64(a, c)
+    costs = {}
+    for contract in (0, 1, 3, 7):
+        mv, _ = oracle_lib.approxmatch(a, c, contract)
+        costs[contract] = oracle_lib.matchcost(a, c, mv).astype(np.float64)
+        assert np.abs(mv - m64).max() < 1e-3, contract
+        np.testing.assert_allclose(costs[contract], c64, rtol=1e-6)
+    for contract in (1, 3, 7):
+        np.testing.assert_allclose(costs[contract], costs[0], rtol=1e-6)
