@@ -8,9 +8,10 @@
 //
 // Design:
 //  * nn_distance: one launch covers both directions.  A workgroup owns 256*R query points of one
-//    cloud (R points per lane in registers) and sweeps the other set through a 16 KB LDS tile of
-//    float4 candidates read as wave-uniform ds_read_b128 broadcasts.  No global round trip of the
-//    running minimum (the reference keeps it in global memory between tiles, nndistance.cu:122).
+//    cloud (R points per lane in registers) and sweeps the other set through a 12 KB LDS tile of
+//    candidate groups read as wave-uniform ds_read_b128 broadcasts into packed fp32 ops.  No global
+//    round trip of the running minimum (the reference keeps it in global memory between tiles,
+//    nndistance.cu:122).
 //  * the approximate matching itself (approxmatch.cu:34-213) is in emd.hip; here: the two kernels that
 //    consume a materialised `match` (MatchCost / MatchCostGrad API parity).
 //  * all reductions are ordered or exact: no float atomics anywhere — the scatter half of nndistancegrad (global
@@ -36,9 +37,29 @@ struct NNDir {
     int* idx;        // (b, n)
 };
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 splat2(float v) { return f2{v, v}; }
+// squared distances of two candidates to one query: per element fma(dz,dz,fma(dy,dy,dx*dx)) — the oracle's chain
+__device__ __forceinline__ f2 sqdist2(f2 dx, f2 dy, f2 dz) {
+    return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+}
+
+// The kernel is bound by vector-instruction issue (820 FLOP per HBM byte): what counts is instructions per pair.
+//  * candidates sit in LDS in groups of four, [x0 x1 y0 y1][z0 z1 x2 x3][y2 y3 z2 z3]: three wave-uniform
+//    ds_read_b128 broadcasts feed packed fp32 ops (v_pk_add/mul/fma_f32: two candidates per instruction, each element
+//    keeping the scalar chain of the oracle, so distances stay bit-identical) — 6 packed ops per candidate pair;
+//  * the running minimum is ONE v_min3_f32 per candidate pair and carries no index.  The arg-min is recovered
+//    afterwards: per 32 candidates (a chunk) one compare notes the last chunk in which the minimum strictly decreased
+//    — the chunk holding the FIRST candidate that attains the final minimum (nndistance.cu:32,122: strict `<` inside
+//    and across tiles) — and at the end the query re-evaluates that one chunk (same instructions, same bits) and takes
+//    the smallest index with d == min.
+//  7 vector instructions per candidate pair and query instead of 18; R = 4 queries per lane share every LDS read.
+constexpr int kChunk = 32;                  // candidates per arg-min chunk (8 groups of 4)
+constexpr int kTileF4 = kTile / 4 * 3;      // float4 per tile
+
 template <int R, bool SUM>
 __global__ __launch_bounds__(kThreads) void nn_distance_kernel(NNDir d1, NNDir d2, int nb1, float* __restrict__ partials) {
-    __shared__ float4 tile[kTile];
+    __shared__ float4 tile[kTileF4];
     __shared__ float red[kThreads / 64];
     const bool second = (int)blockIdx.x >= nb1;
     const NNDir a = second ? d2 : d1;
@@ -48,36 +69,58 @@ __global__ __launch_bounds__(kThreads) void nn_distance_kernel(NNDir d1, NNDir d
     const float* Q = a.q + (size_t)cloud * a.n * 3;
     const float* C = a.c + (size_t)cloud * a.m * 3;
 
-    float qx[R], qy[R], qz[R], best[R];
-    int bi[R];
+    f2 qx[R], qy[R], qz[R];
+    float run[R], seen[R];
+    int chunk[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int j = bx * (kThreads * R) + r * kThreads + tid;
-        qx[r] = qy[r] = qz[r] = 0.f;
+        float x = 0.f, y = 0.f, z = 0.f;
         if (j < a.n) {
-            qx[r] = Q[j * 3 + 0];
-            qy[r] = Q[j * 3 + 1];
-            qz[r] = Q[j * 3 + 2];
+            x = Q[j * 3 + 0];
+            y = Q[j * 3 + 1];
+            z = Q[j * 3 + 2];
         }
-        best[r] = __builtin_inff();
-        bi[r] = 0;
+        qx[r] = splat2(x);
+        qy[r] = splat2(y);
+        qz[r] = splat2(z);
+        run[r] = seen[r] = __builtin_inff();
+        chunk[r] = 0;
     }
+    const float kInf = __builtin_inff();
     for (int k0 = 0; k0 < a.m; k0 += kTile) {
         const int cnt = min(kTile, a.m - k0);
-        for (int t = tid; t < cnt; t += kThreads) {
-            const float* s = C + (size_t)(k0 + t) * 3;
-            tile[t] = make_float4(s[0], s[1], s[2], 0.f);
+        const int groups = (cnt + kChunk - 1) / kChunk * (kChunk / 4);   // whole chunks; candidates past m sit at +inf
+        for (int g = tid; g < groups; g += kThreads) {
+            float v[12];
+#pragma unroll
+            for (int u = 0; u < 12; ++u) {
+                const int k = g * 4 + u / 3;
+                v[u] = k < cnt ? C[(size_t)(k0 + k) * 3 + u % 3] : kInf;
+            }
+            tile[g * 3 + 0] = make_float4(v[0], v[3], v[1], v[4]);
+            tile[g * 3 + 1] = make_float4(v[2], v[5], v[6], v[9]);
+            tile[g * 3 + 2] = make_float4(v[7], v[10], v[8], v[11]);
         }
         __syncthreads();
-#pragma unroll 8
-        for (int k = 0; k < cnt; ++k) {
-            const float4 c = tile[k];
+        for (int c = 0; c < groups; c += kChunk / 4) {
+#pragma unroll
+            for (int g = 0; g < kChunk / 4; ++g) {
+                const float4 A = tile[(c + g) * 3 + 0], B = tile[(c + g) * 3 + 1], D = tile[(c + g) * 3 + 2];
+                const f2 x01{A.x, A.y}, y01{A.z, A.w}, z01{B.x, B.y}, x23{B.z, B.w}, y23{D.x, D.y}, z23{D.z, D.w};
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const f2 e = sqdist2(x01 - qx[r], y01 - qy[r], z01 - qz[r]);
+                    const f2 f = sqdist2(x23 - qx[r], y23 - qy[r], z23 - qz[r]);
+                    run[r] = __builtin_fminf(__builtin_fminf(run[r], e.x), e.y);
+                    run[r] = __builtin_fminf(__builtin_fminf(run[r], f.x), f.y);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const float d = hp::sqdist(c.x - qx[r], c.y - qy[r], c.z - qz[r]);
-                if (d < best[r]) {  // strict: the smallest index wins ties (nndistance.cu:32,122)
-                    best[r] = d;
-                    bi[r] = k0 + k;
+                if (run[r] < seen[r]) {   // strictly smaller: this chunk holds the first candidate at the new minimum
+                    seen[r] = run[r];
+                    chunk[r] = k0 + c * 4;
                 }
             }
         }
@@ -88,9 +131,20 @@ __global__ __launch_bounds__(kThreads) void nn_distance_kernel(NNDir d1, NNDir d
     for (int r = 0; r < R; ++r) {
         const int j = bx * (kThreads * R) + r * kThreads + tid;
         if (j < a.n) {
-            a.dist[(size_t)cloud * a.n + j] = best[r];
-            a.idx[(size_t)cloud * a.n + j] = bi[r];
-            s += best[r];
+            // the winning chunk again, from memory: the smallest index whose distance equals the minimum
+            int bi = chunk[r];
+#pragma unroll 4
+            for (int u = kChunk - 1; u >= 0; --u) {
+                const int k = chunk[r] + u;
+                if (k < a.m) {
+                    const float* p = C + (size_t)k * 3;
+                    const float d = hp::sqdist(p[0] - qx[r].x, p[1] - qy[r].x, p[2] - qz[r].x);
+                    if (d == seen[r]) bi = k;
+                }
+            }
+            a.dist[(size_t)cloud * a.n + j] = seen[r];
+            a.idx[(size_t)cloud * a.n + j] = bi;
+            s += seen[r];
         }
     }
     if (SUM) {
@@ -353,19 +407,28 @@ __global__ __launch_bounds__(kThreads) void matchcostgrad2_kernel(int n, int m, 
     }
 }
 
-constexpr int kNNR = 2;  // query points per lane
-
-inline int nn_blocks(int n) { return (n + kThreads * kNNR - 1) / (kThreads * kNNR); }
+// Query points per lane: 4 when that still gives every CU two workgroups (each LDS read then feeds 4 x 14 vector
+// instructions), else 2, else 1 (B=64, N=2048: 2 -> 512 workgroups; N=8192: 4 -> 1024).
+inline int nn_blocks(int n, int r) { return (n + kThreads * r - 1) / (kThreads * r); }
+inline int nn_pick_r(int b, int n, int m) {
+    for (int r = 4; r > 1; r >>= 1)
+        if ((long)b * (nn_blocks(n, r) + nn_blocks(m, r)) >= 512) return r;
+    return 1;
+}
 
 template <bool SUM>
 int launch_nn(int b, int n, const float* xyz, int m, const float* xyz2, float* result, int* result_i, float* result2,
-              int* result2_i, float* partials, hipStream_t stream) {
+              int* result2_i, float* partials, int* blocks_per_cloud, hipStream_t stream) {
     if (b <= 0 || (n <= 0 && m <= 0)) return 0;
     NNDir d1{n, xyz, m, xyz2, result, result_i};
     NNDir d2{m, xyz2, n, xyz, result2, result2_i};
-    const int nb1 = nn_blocks(n), nb2 = nn_blocks(m);
+    const int r = nn_pick_r(b, n, m);
+    const int nb1 = nn_blocks(n, r), nb2 = nn_blocks(m, r);
+    if (blocks_per_cloud) *blocks_per_cloud = nb1 + nb2;
     dim3 grid(nb1 + nb2, b);
-    hipLaunchKernelGGL((nn_distance_kernel<kNNR, SUM>), grid, dim3(kThreads), 0, stream, d1, d2, nb1, partials);
+    if (r == 4) hipLaunchKernelGGL((nn_distance_kernel<4, SUM>), grid, dim3(kThreads), 0, stream, d1, d2, nb1, partials);
+    else if (r == 2) hipLaunchKernelGGL((nn_distance_kernel<2, SUM>), grid, dim3(kThreads), 0, stream, d1, d2, nb1, partials);
+    else hipLaunchKernelGGL((nn_distance_kernel<1, SUM>), grid, dim3(kThreads), 0, stream, d1, d2, nb1, partials);
     return (int)hipGetLastError();
 }
 
@@ -379,7 +442,8 @@ int launch_nn(int b, int n, const float* xyz, int m, const float* xyz2, float* r
 HP_API int hp_nndistance(int b, int n, const float* xyz, int m, const float* xyz2, float* result, int* result_i,
                          float* result2, int* result2_i, hipStream_t stream) {
     HP_CHECK_ARG(b >= 0 && n >= 0 && m >= 0);
-    return launch_nn<false>(b, n, xyz, m, xyz2, result, result_i, result2, result2_i, nullptr, stream);
+    HP_CHECK_ARG(b <= 65535);
+    return launch_nn<false>(b, n, xyz, m, xyz2, result, result_i, result2, result2_i, nullptr, nullptr, stream);
 }
 
 // replaces nndistancegrad(...)  structural_loss.cpp:15 / nndistance.cu:155-160.
@@ -401,7 +465,7 @@ HP_API int hp_nndistancegrad(int b, int n, const float* xyz1, int m, const float
 }
 
 // number of floats hp_chamfer_forward needs in `partials`
-HP_API long hp_chamfer_workspace_floats(int b, int n, int m) { return (long)b * (nn_blocks(n) + nn_blocks(m)); }
+HP_API long hp_chamfer_workspace_floats(int b, int n, int m) { return (long)b * (nn_blocks(n, 1) + nn_blocks(m, 1)); }
 
 // Fused Chamfer forward: losses/champfer_loss.py:11-17 on (preds (b,n,3), gts (b,m,3)).
 //   loss[0] = sum_b [ sum_i min_j |p_i-g_j|^2 + sum_j min_i |p_i-g_j|^2 ]   (batch SUM)
@@ -409,10 +473,11 @@ HP_API long hp_chamfer_workspace_floats(int b, int n, int m) { return (long)b * 
 // path expands |x|^2+|y|^2-2xy; the two agree to ~1e-7).
 HP_API int hp_chamfer_forward(int b, int n, const float* preds, int m, const float* gts, float* dist1, int* idx1,
                               float* dist2, int* idx2, float* partials, float* loss, hipStream_t stream) {
-    HP_CHECK_ARG(b > 0 && n > 0 && m > 0);
-    int rc = launch_nn<true>(b, n, preds, m, gts, dist1, idx1, dist2, idx2, partials, stream);
+    HP_CHECK_ARG(b > 0 && b <= 65535 && n > 0 && m > 0);
+    int per_cloud = 0;
+    int rc = launch_nn<true>(b, n, preds, m, gts, dist1, idx1, dist2, idx2, partials, &per_cloud, stream);
     if (rc) return rc;
-    const int count = b * (nn_blocks(n) + nn_blocks(m));
+    const int count = b * per_cloud;
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, partials, count, loss);
     HP_RETURN_LAST_ERROR();
 }
