@@ -109,9 +109,13 @@ class TrainEngine:
         self.exchange = self.reducer.active      # world > 1, or a one-rank group asked to run the collectives anyway
         self.exp_avg = torch.zeros_like(self.flat.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat.flat)
-        self.steps = 0
+        self.steps = 0             # completed optimisation steps
+        self._adam_step = 0        # the step number the Adam launches of the step in flight use (bias correction)
         self._heads_pending = False
         model._pre_hypernet_hook = self.finish_pending     # FullModel.forward calls it right before the hypernetwork
+        # A reader of the parameters outside `step` (model.state_dict(), torch.save: core/main.py:164) must not see the
+        # hypernetwork one step behind the encoders or half-gathered rows: flush the deferred updates first.
+        self._sd_hook = model.register_state_dict_pre_hook(lambda *_: self.synchronize())
         self._consts = {}
         # the heads' update: sharded over the ranks (HeadsShard) when the layout allows it, else all-reduced like the rest
         self.shard = None
@@ -146,7 +150,7 @@ class TrainEngine:
                                 list(gt.shape), epoch, device, points=points, eps=eps_noise)
         rec_n3 = rec.permute(0, 2, 1)
         roots, root_grads, out = self._losses_and_gradients(gt, rec_n3, logvar, mu)
-        self.steps += 1
+        self._adam_step = self.steps + 1      # `steps` itself moves only once backward has succeeded
         if self.exchange:
             # the hypernetwork's gradients (90 % of the bytes) are complete once its backward has been
             # enqueued; ship them while the encoders' backward still runs
@@ -157,6 +161,7 @@ class TrainEngine:
             torch.autograd.backward(roots, root_grads)
         finally:
             ops.HEADS_DW_EXCHANGE = None
+        self.steps = self._adam_step
         # Exchange + update per bucket.  The encoders' bucket (6.6 MB) is reduced and updated now: the next step starts
         # with it.  The hypernetwork's buckets (heads 156 MB, trunk 11 MB: 96 % of the bytes) are only needed again in the
         # NEXT step's hypernetwork forward, which comes after ~1 ms of encoder forward: their all-reduces stay in flight
@@ -265,7 +270,7 @@ class TrainEngine:
 
     def _adam_range(self, lo, hi):
         ops.adam_step(self.flat.flat[lo:hi], self.flat.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.lr,
-                      self.betas[0], self.betas[1], self.eps, self.steps)
+                      self.betas[0], self.betas[1], self.eps, self._adam_step)
 
     def finish_pending(self):
         """Complete the deferred hypernetwork updates (idempotent).  Call before reading the parameters outside `step`."""
@@ -280,6 +285,62 @@ class TrainEngine:
                     self.reducer.wait(b)
                     self._adam(b)
             self._heads_pending = False
+
+    def synchronize(self):
+        """finish_pending + wait for the device: after it the parameters are the state after `steps` whole steps."""
+        self.finish_pending()
+        torch.cuda.current_stream(self.flat.flat.device).synchronize()
+
+    # ------------------------------------------------------------------ optimiser checkpoints (SURVEY §8f N1)
+    def _moment_views(self, buf):
+        """Per-parameter views of a flat moment buffer, in `model.parameters()` order — the order the reference builds its
+        Adam in (core/main.py:62-66), hence the index space of its `{epoch}_O.pth` files."""
+        off = {id(p): o for p, o in zip(self.flat.params, self.flat.offsets)}
+        return [buf[off[id(p)]:off[id(p)] + p.numel()].view(p.shape) for p in self.model.parameters()]
+
+    def _full_moments(self):
+        """exp_avg / exp_avg_sq with every rank's rows of the sharded heads gathered (collective under DP)."""
+        m, v = self.exp_avg.clone(), self.exp_avg_sq.clone()
+        if self.shard is not None and self.world > 1:
+            sh = self.shard
+            lo = sh.lo + sh.r0 * sh.cols
+            hi = lo + sh.R * sh.cols
+            for full, own in ((m, self.exp_avg), (v, self.exp_avg_sq)):
+                dist.all_gather_into_tensor(full[sh.lo:sh.hi], own[lo:hi].clone(), group=self.reducer.pg)
+        return m, v
+
+    def optimizer_state_dict(self):
+        """The optimiser state in `torch.optim.Adam.state_dict()` format, i.e. what the reference saves as `{epoch}_O.pth`
+        (core/main.py:165) and restores with `optimizer.load_state_dict` (core/setup.py:96-97): loadable into a
+        torch.optim.Adam over `full_model.parameters()` and back.  Under data parallelism the heads' moments live
+        row-sharded on the ranks: every rank must call this (one all-gather), every rank gets the full state."""
+        self.synchronize()
+        m, v = self._full_moments()
+        params = list(self.model.parameters())
+        group = dict(torch.optim.Adam([torch.zeros(1)], lr=self.lr, betas=self.betas, eps=self.eps).state_dict()["param_groups"][0])
+        group["params"] = list(range(len(params)))
+        state = {}
+        if self.steps > 0:
+            for i, (mi, vi) in enumerate(zip(self._moment_views(m), self._moment_views(v))):
+                state[i] = {"step": torch.tensor(float(self.steps)), "exp_avg": mi.clone(), "exp_avg_sq": vi.clone()}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd):
+        """Inverse of optimizer_state_dict (also accepts a reference `{epoch}_O.pth`).  Parameters without an entry (never
+        stepped: real_encoder.std_layer in HyperPocket mode) keep zero moments."""
+        self.synchronize()
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps = float(g["lr"]), tuple(float(b) for b in g["betas"]), float(g["eps"])
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        steps = 0
+        mv, vv = self._moment_views(self.exp_avg), self._moment_views(self.exp_avg_sq)
+        for i, st in sd["state"].items():
+            i = int(i)
+            mv[i].copy_(st["exp_avg"].to(mv[i].device).view_as(mv[i]))
+            vv[i].copy_(st["exp_avg_sq"].to(vv[i].device).view_as(vv[i]))
+            steps = max(steps, int(float(st["step"])))
+        self.steps = self._adam_step = steps
 
     def _install_overlap_hook(self):
         # fires when autograd has finished the HyperNetFunction node, i.e. when the gradient w.r.t. the latent exists

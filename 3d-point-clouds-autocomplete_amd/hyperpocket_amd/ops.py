@@ -49,7 +49,15 @@ _GRAD_VIEWS = {}
 
 
 def register_grad_view(param, view):
+    """Returns the registry key; the owner drops its keys when it dies (parallel.FlatParameters does, through a
+    weakref finalizer), so a dead engine's flat gradient buffer is not pinned by this table."""
     _GRAD_VIEWS[param.data_ptr()] = view
+    return param.data_ptr()
+
+
+def drop_grad_views(keys):
+    for k in keys:
+        _GRAD_VIEWS.pop(k, None)
 
 
 def clear_grad_views():
@@ -150,6 +158,13 @@ class HyperNetFunction(Function):
     def forward(ctx, latent, n_heads, *params):
         latent = latent.contiguous()
         check_input(latent, "latent")
+        # raw pointers go to the kernels: a head left on the CPU (`freeze_layers_learning` keeps `output` a plain list,
+        # which .cuda() does not move — model/hyper_network.py:38-39), a .half() / .double() model or a foreign device must
+        # fail here, not as a GPU memory fault
+        for i, p in enumerate(params):
+            check_input(p, f"hypernetwork param {i}")
+            if p.device != latent.device:
+                raise HipExtensionError(f"hypernetwork param {i} is on {p.device}, the latent on {latent.device}")
         B, in_size = latent.shape
         dev = latent.device
         w = _HyperWeights()

@@ -11,6 +11,8 @@ been enqueued, so it travels while the encoder backward (the bulk of the FLOPs) 
 Loss semantics under sharding: the Chamfer term is a batch SUM, so gradients are
 summed, never averaged; the KLD term is divided by the GLOBAL batch (engine passes B_local*world).
 """
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -71,12 +73,15 @@ class FlatParameters:
         self.buckets = [tuple(bounds[b]) for b in sorted(bounds)]
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        keys = []
         with torch.no_grad():
             for p, o in zip(self.params, offs):
                 view = self.flat[o:o + p.numel()].view(p.shape)
                 view.copy_(p.data)
                 p.data = view                              # the Parameter object (and any optimizer reference) survives
-                ops.register_grad_view(p, self.grad[o:o + p.numel()].view(p.shape))
+                keys.append(ops.register_grad_view(p, self.grad[o:o + p.numel()].view(p.shape)))
+        # the registry is process-global: drop this owner's entries with the owner (they pin the flat gradient buffer)
+        self._finalizer = weakref.finalize(self, ops.drop_grad_views, keys)
 
     def is_intact(self):
         return all(p.data_ptr() == self.flat.data_ptr() + 4 * o for p, o in zip(self.params, self.offsets))

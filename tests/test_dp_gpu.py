@@ -62,8 +62,10 @@ def _worker(rank, world, port, out, shard):
                        eps_noise=eps[sl].contiguous())
     eng.finish_pending()       # the heads' exchange/update is deferred into the next step; flush it before reading
     torch.cuda.synchronize()
+    osd = eng.optimizer_state_dict()     # collective: gathers the row-sharded moments of the heads
     if rank == 0:   # by file: a 173 MB dict does not travel well through an mp.Queue once the sender exits
-        torch.save({k: p.detach().cpu() for k, p in model.named_parameters()}, out)
+        torch.save({"params": {k: p.detach().cpu() for k, p in model.named_parameters()},
+                    "opt": {i: {k: v.cpu() for k, v in st.items()} for i, st in osd["state"].items()}}, out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -87,7 +89,8 @@ def test_two_rank_engine_matches_single_process_global_batch(shard):
     for p in procs:
         p.join(timeout=600)
         assert p.exitcode == 0
-    got = torch.load(out)
+    saved = torch.load(out)
+    got, got_opt = saved["params"], saved["opt"]
     os.remove(out)
     model = _build()
     eng = TrainEngine(model, emd_coef=0.05)
@@ -101,6 +104,15 @@ def test_two_rank_engine_matches_single_process_global_batch(shard):
             # Adam's update is ~lr*sign(g): tiny-gradient elements may flip under a different summation order
             assert (a - b).abs().max().item() <= 2.5e-4, k
             assert (a - b).abs().mean().item() <= 2e-6, k
+        # the optimiser checkpoint written under DP (heads' Adam moments row-sharded over the ranks, gathered by
+        # optimizer_state_dict) equals the single-process optimiser state on the global batch
+        want_opt = eng.optimizer_state_dict()["state"]
+        assert sorted(got_opt) == sorted(want_opt)
+        for i, st in want_opt.items():
+            assert float(got_opt[i]["step"]) == float(st["step"]) == 2.0
+            for key in ("exp_avg", "exp_avg_sq"):
+                a, b = got_opt[i][key].double(), st[key].cpu().double()
+                assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item() + 1e-12, (i, key)
     finally:
         ops.clear_grad_views()
 

@@ -664,6 +664,124 @@ def test_baseline_config4_hyperrec_full_size_step(ref):
         ops.clear_grad_views()
 
 
+def test_baseline_config3_missing_shapenet_per_gpu_step(ref, oracle_lib):
+    """BASELINE.json configs[2] (MissingShapeNet, B=128 over 2 GPUs) per-GPU shape = the metric's shape: HyperPocket
+    128+128, B=64, existing/missing (64,1024,3), gt (64,2048,3), loss 0.05*Chamfer + KLD/B + 0.05*EMD/N.
+    One engine step at full size, checked against the oracle on a 4-cloud slice: the step is per-cloud independent
+    (no BatchNorm), so rec / mu / exp(logvar) of clouds {0,21,42,63} must equal the oracle run on those 4
+    clouds alone, and the batch losses must equal the sums of the per-cloud terms the kernels report."""
+    from hyperpocket_amd.core.engine import TrainEngine
+    from hyperpocket_amd import ops
+    from hyperpocket_amd.losses.champfer_loss import ChamferLoss
+    from hyperpocket_amd.utils.pytorch_structural_losses.match_cost import match_cost
+    model = build_model(2020)
+    P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(64)
+    ex, mi = torch.rand(64, 1024, 3, generator=g) - 0.5, torch.rand(64, 1024, 3, generator=g) - 0.5
+    gt = torch.cat([ex, mi], 1)
+    pts, eps = torch.rand(64, 2048, 3, generator=g) * 2 - 1, torch.randn(64, 128, generator=g)
+    pick = [0, 21, 42, 63]
+    # drop-in route at B=64: outputs of the picked clouds vs the oracle on the slice
+    model.train()
+    rec, explv, mu = model(ex.clone().cuda(), mi.clone().cuda(), [64, 2048, 3], 1, torch.device("cuda"), points=pts.cuda(),
+                           eps=eps.cuda())
+    want_rec, want_lv, want_mu, _ = ref.full_forward(P, ex[pick], mi[pick], pts[pick], eps=eps[pick], training=True)
+    close_scaled(rec[pick], want_rec)
+    close_scaled(mu[pick], want_mu)
+    close_scaled(explv[pick], want_lv)
+    rec_n3 = rec.detach().permute(0, 2, 1).contiguous()
+    explv, mu = explv.detach(), mu.detach()
+    cd_slice = ChamferLoss()(gt[pick].cuda(), rec_n3[pick].contiguous()).item()
+    want_cd = ref.chamfer_loss(gt[pick], want_rec.permute(0, 2, 1)).item()
+    assert abs(cd_slice - want_cd) <= 1e-5 * abs(want_cd)
+    emd_slice = match_cost(gt[pick].cuda(), rec_n3[pick].contiguous()).cpu().numpy()
+    rr = rec_n3[pick].cpu().numpy()
+    om, _ = oracle_lib.approxmatch(gt[pick].numpy(), rr)
+    np.testing.assert_allclose(emd_slice, oracle_lib.matchcost(gt[pick].numpy(), rr, om), rtol=1e-5)
+    # the engine's step at B=64: batch losses = sums over the batch of what the drop-in route reports
+    cd_all = ChamferLoss()(gt.cuda(), rec_n3).item()
+    emd_all = match_cost(gt.cuda(), rec_n3).double().sum().item()
+    kld_all = (0.5 * (torch.exp(explv.double()) + mu.double() ** 2 - 1 - explv.double()).sum() / 64).item()
+    eng = TrainEngine(model, emd_coef=0.05)
+    try:
+        out = eng.step(ex.cuda(), mi.cuda(), gt.cuda(), 1, points=pts.cuda(), eps_noise=eps.cuda())
+        assert abs(out["loss_r"].item() - 0.05 * cd_all) <= 1e-5 * 0.05 * cd_all
+        assert abs(out["loss_kld"].item() - kld_all) <= 1e-5 * abs(kld_all)
+        assert abs(out["loss_emd"].item() - 0.05 * emd_all / 2048) <= 1e-5 * 0.05 * emd_all / 2048
+        assert abs(out["loss_all"].item() - (0.05 * cd_all + kld_all + 0.05 * emd_all / 2048)) <= 1e-5 * abs(out["loss_all"].item())
+        eng.synchronize()
+        for k, p in model.named_parameters():
+            assert torch.isfinite(p).all(), k
+        # Adam moved every trained parameter by about lr (std_layer of the plain encoder never trains: SURVEY Q8)
+        moved = {k: (p.detach().cpu() - P[k]).abs().max().item() for k, p in model.named_parameters()}
+        assert moved["real_encoder.std_layer.weight"] == 0.0
+        assert 0.5e-4 < moved["hyper_network.output.3.weight"] <= 1.01e-4 and 0.5e-4 < moved["random_encoder.conv.0.weight"] <= 1.01e-4
+    finally:
+        ops.clear_grad_views()
+
+
+def test_engine_optimizer_checkpoint_round_trip():
+    """N1 under the engine: optimizer_state_dict() is a torch.optim.Adam state dict in `full_model.parameters()` order (what
+    the reference saves as {epoch}_O.pth, core/main.py:165); saving model + optimiser after two steps and loading both
+    into a fresh engine gives a bit-identical third step; torch.optim.Adam itself accepts the dict."""
+    from hyperpocket_amd.core.engine import TrainEngine
+    from hyperpocket_amd import ops
+    g = torch.Generator().manual_seed(11)
+    ex, mi = (torch.rand(3, 96, 3, generator=g) - 0.5).cuda(), (torch.rand(3, 96, 3, generator=g) - 0.5).cuda()
+    gt = torch.cat([ex, mi], 1)
+    pts, eps = (torch.rand(3, 192, 3, generator=g) * 2 - 1).cuda(), torch.randn(3, 128, generator=g).cuda()
+    a = build_model(31)
+    ea = TrainEngine(a, emd_coef=0.05)
+    try:
+        for _ in range(2):
+            ea.step(ex, mi, gt, 3, points=pts, eps_noise=eps)
+        msd = {k: v.detach().cpu().clone() for k, v in a.state_dict().items()}     # the pre-hook flushes the deferred updates
+        osd = ea.optimizer_state_dict()
+        n_params = len(list(a.parameters()))
+        assert sorted(osd["state"]) == list(range(n_params)) and osd["param_groups"][0]["params"] == list(range(n_params))
+        assert all(float(st["step"]) == 2.0 for st in osd["state"].values())
+        ref_opt = torch.optim.Adam(a.parameters(), lr=1e-4)
+        ref_opt.load_state_dict(osd)                                                 # the reference's restore path accepts it
+        i_w = [i for i, p in enumerate(a.parameters()) if p is a.hyper_network.output[3].weight][0]
+        assert torch.equal(ref_opt.state[a.hyper_network.output[3].weight]["exp_avg"].cpu(), osd["state"][i_w]["exp_avg"].cpu())
+        ea.step(ex, mi, gt, 3, points=pts, eps_noise=eps)
+        ea.synchronize()
+        want = {k: v.detach().cpu().clone() for k, v in a.state_dict().items()}
+    finally:
+        ops.clear_grad_views()
+    b = build_model(77)                                   # different weights: everything must come from the checkpoint
+    eb = TrainEngine(b, emd_coef=0.05)
+    try:
+        b.load_state_dict(msd)
+        assert eb.flat.is_intact()
+        eb.load_optimizer_state_dict(ref_opt.state_dict())   # ... and torch's own re-export of it loads back
+        assert eb.steps == 2
+        eb.step(ex, mi, gt, 3, points=pts, eps_noise=eps)
+        eb.synchronize()
+        for k, v in b.state_dict().items():
+            assert torch.equal(v.detach().cpu(), want[k]), k
+    finally:
+        ops.clear_grad_views()
+
+
+def test_hypernetwork_rejects_parameters_the_kernels_cannot_read():
+    """`freeze_layers_learning: true` keeps HyperNetwork.output a plain list (model/hyper_network.py:38-39), which .cuda()
+    does not move: the reference then fails with a device-mismatch RuntimeError; raw pointers would fault the GPU."""
+    from hyperpocket_amd import HipExtensionError
+    from hyperpocket_amd.model.full_model import FullModel
+    cfg = copy.deepcopy(model_config())
+    cfg["target_network"]["freeze_layers_learning"] = True
+    torch.manual_seed(1)
+    model = FullModel(cfg).cuda()
+    assert not model.hyper_network.output[0].weight.is_cuda
+    x = torch.rand(2, 64, 3, device="cuda")
+    with pytest.raises(HipExtensionError):
+        model(x.clone(), x.clone(), [2, 128, 3], 1, torch.device("cuda"))
+    model = build_model(3).double()
+    with pytest.raises(HipExtensionError):
+        model(x.clone(), x.clone(), [2, 128, 3], 1, torch.device("cuda"))
+
+
 def test_baseline_config5_chamfer_stress_shape():
     """BASELINE.json configs[4] per-GPU shape: 64 clouds of 8192 points, Chamfer forward + backward."""
     from hyperpocket_amd.losses.champfer_loss import ChamferLoss
