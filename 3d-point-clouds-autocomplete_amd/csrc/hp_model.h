@@ -45,3 +45,10 @@ typedef struct HpHyperGrads {
     float* head_w[HP_MAX_HEADS];
     float* head_b[HP_MAX_HEADS];
 } HpHyperGrads;
+
+#ifdef __cplusplus
+/* hypernet.hip (internal): fragment-direct heads kernels */
+bool hp_heads_dw_fast_ok(int cols, const float* t5, const float* out);
+int hp_heads_dw_launch(int Kc, int rows, int r0, const float* dtheta, int theta_ld, const float* t5, int cols, float* dW,
+                       hipStream_t stream);
+#endif

@@ -26,9 +26,9 @@ class HeadsShard:
     the all-reduce, and nothing of it is on the critical path: it is waited for right before the NEXT step's
     hypernetwork forward).  Every rank must run the same batch size."""
 
-    def __init__(self, flat, reducer, adam_range):
+    def __init__(self, flat, reducer, adam_rows):
         h = flat.heads
-        self.flat, self.reducer, self.adam_range = flat, reducer, adam_range
+        self.flat, self.reducer, self.adam_rows = flat, reducer, adam_rows
         self.world, self.rank = reducer.world, reducer.rank
         self.lo, self.rows, self.cols = h["lo"], h["rows"], h["cols"]
         self.R = h["pad_rows"] // self.world                      # rows owned per rank (pad rows: zero weights, zero grads)
@@ -81,9 +81,10 @@ class HeadsShard:
         lo = self.lo + self.r0 * self.cols
         hi = lo + self.R * self.cols
         if self.rows_here:
-            call("hp_hypernet_heads_dw_rows", dth.size(0), self.rows_here, self.r0, dth, dth.size(1), t5,
-                 flat.grad[lo:lo + self.rows_here * self.cols], ws, current_stream(dth.device))
-        self.adam_range(lo, hi)
+            # this rank's rows of the GLOBAL gradient and their Adam update in one pass (the rows' gradient is never stored;
+            # the padding rows past 19011 have zero weights and zero gradients: nothing to do)
+            n = self.rows_here * self.cols
+            self.adam_rows(dth, t5, self.r0, self.rows_here, lo, lo + n)
         self.reducer.all_gather("heads_w", flat.flat[self.lo:self.hi], flat.flat[lo:hi])
         self.weights_in_flight = True
         self.pending = False
@@ -95,11 +96,37 @@ class HeadsShard:
             self.weights_in_flight = False
 
 
+class FusedHeadsAdam:
+    """One GPU: the heads' weight gradient (dW = d theta^T . t5, 156 MB) is never materialised — right behind the
+    hypernetwork backward (which still needs the OLD weights for d t5 = d theta . W) one kernel forms it tile by tile in
+    registers and applies Adam to W / exp_avg / exp_avg_sq in place (hp_hypernet_heads_dw_adam): 6 x 156 MB of HBM traffic
+    instead of the 8 x 156 MB of "write dW, then one Adam pass over it", and the step's last Adam pass shrinks to the
+    17 MB of everything else.  Same object protocol as HeadsShard (ops.HEADS_DW_EXCHANGE)."""
+
+    def __init__(self, engine):
+        h = engine.flat.heads
+        self.engine, self.flat = engine, engine.flat
+        self.lo, self.hi, self.rows, self.cols = h["lo"], h["hi"], h["rows"], h["cols"]
+
+    accepts = HeadsShard.accepts
+
+    def begin(self, grad_theta, t5):
+        pass                                   # nothing to exchange
+
+    def finish(self, grad_theta, t5):
+        """Called by HyperNetFunction.backward AFTER hp_hypernet_backward has been enqueued (stream order: after d t5)."""
+        e = self.engine
+        n = self.rows * self.cols
+        call("hp_hypernet_heads_dw_adam", grad_theta.size(0), self.rows, 0, grad_theta, grad_theta.size(1), t5,
+             self.flat.flat[self.lo:self.lo + n], e.exp_avg[self.lo:self.lo + n], e.exp_avg_sq[self.lo:self.lo + n],
+             float(e.lr), float(e.betas[0]), float(e.betas[1]), float(e.eps), int(e._adam_step), current_stream(grad_theta.device))
+
+
 class TrainEngine:
     _DEFERRED = (1, 0)   # buckets whose exchange + update cross the step boundary when world > 1: trunk, heads
 
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, loss_coef=0.05, emd_coef=0.0, process_group=None,
-                 force_exchange=False, shard_heads=True):
+                 force_exchange=False, shard_heads=True, fuse_heads_adam=True):
         self.model = model
         self.lr, self.betas, self.eps = lr, betas, eps
         self.loss_coef, self.emd_coef = loss_coef, emd_coef
@@ -120,7 +147,12 @@ class TrainEngine:
         # the heads' update: sharded over the ranks (HeadsShard) when the layout allows it, else all-reduced like the rest
         self.shard = None
         if self.exchange and shard_heads and HeadsShard.usable(self.flat, self.world):
-            self.shard = HeadsShard(self.flat, self.reducer, self._adam_range)
+            self.shard = HeadsShard(self.flat, self.reducer, self._adam_heads_rows)
+        # one rank: the heads' dW and its Adam update are one kernel (the gradient of the heads' weights is then never
+        # stored: their .grad stays None)
+        self.fused = None
+        if not self.exchange and fuse_heads_adam and HeadsShard.usable(self.flat, 1):
+            self.fused = FusedHeadsAdam(self)
         if self.exchange:
             # replicas start from rank 0's weights
             dist.broadcast(self.flat.flat, src=0, group=process_group)
@@ -157,6 +189,8 @@ class TrainEngine:
             self._install_overlap_hook()
             if self.shard is not None:
                 ops.HEADS_DW_EXCHANGE = self.shard
+        elif self.fused is not None:
+            ops.HEADS_DW_EXCHANGE = self.fused
         try:
             torch.autograd.backward(roots, root_grads)
         finally:
@@ -168,7 +202,9 @@ class TrainEngine:
         # across the step boundary and `finish_pending` (called by FullModel.forward right before the hypernetwork)
         # waits for them and applies their Adam updates there.
         if not self.exchange:
-            self._adam_range(0, self.flat.total)     # nothing to exchange: one pass over the whole flat buffer
+            # nothing to exchange: one pass over the flat buffer (minus the heads' weights when their update was fused
+            # into the hypernetwork backward)
+            self._adam_range(self.fused.hi if self.fused is not None else 0, self.flat.total)
             self._heads_pending = False
             return out
         if self.shard is not None:
@@ -271,6 +307,11 @@ class TrainEngine:
     def _adam_range(self, lo, hi):
         ops.adam_step(self.flat.flat[lo:hi], self.flat.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.lr,
                       self.betas[0], self.betas[1], self.eps, self._adam_step)
+
+    def _adam_heads_rows(self, dtheta_all, t5_all, r0, rows, lo, hi):
+        call("hp_hypernet_heads_dw_adam", dtheta_all.size(0), rows, r0, dtheta_all, dtheta_all.size(1), t5_all,
+             self.flat.flat[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], float(self.lr), float(self.betas[0]),
+             float(self.betas[1]), float(self.eps), int(self._adam_step), current_stream(dtheta_all.device))
 
     def finish_pending(self):
         """Complete the deferred hypernetwork updates (idempotent).  Call before reading the parameters outside `step`."""

@@ -145,9 +145,10 @@ class EncoderFunction(Function):
         return (None, None, None, *out)
 
 
-# Data parallelism: an object with `accepts(head_weights) -> bool` and `begin(grad_theta, t5)` (core/engine.py
-# HeadsShard).  When set and accepting, the hypernetwork backward leaves the heads' weight gradient to it: the ranks
-# exchange the gradient's two factors (d theta, t5) instead of the 156 MB matrix.
+# An object with `accepts(head_weights) -> bool`, `begin(grad_theta, t5)` and optionally `finish(grad_theta, t5)`
+# (core/engine.py: HeadsShard under data parallelism, FusedHeadsAdam on one GPU).  When set and accepting, the
+# hypernetwork backward leaves the heads' weight gradient to it: the ranks exchange the gradient's two factors
+# (d theta, t5) instead of the 156 MB matrix / one kernel forms the gradient and applies Adam without storing it.
 HEADS_DW_EXCHANGE = None
 
 
@@ -209,6 +210,10 @@ class HyperNetFunction(Function):
         ws = torch.empty((_long_fn("hp_hypernet_backward_workspace_floats", B),), dtype=torch.float32, device=dev)
         call("hp_hypernet_backward", B, in_size, latent, ctypes.byref(w), t, grad_theta, grad_theta.size(1), ctypes.byref(gr),
              grad_latent, ws, current_stream(dev))
+        if external_dw and hasattr(exch, "finish"):
+            # in-place consumers of the heads' weights (the fused dW + Adam pass) go behind the backward that reads them
+            o5 = _long_fn("hp_hypernet_t5_offset", B)
+            exch.finish(grad_theta, t[o5:o5 + B * 2048].view(B, 2048))
         return (grad_latent, None, *out)
 
 

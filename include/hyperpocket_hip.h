@@ -224,6 +224,14 @@ long hp_hypernet_heads_dw_workspace_floats(void);
 int hp_hypernet_heads_dw_rows(int Kc, int rows, int r0, const float* dtheta_all, int theta_ld, const float* t5_all,
                               float* dW_rows, float* ws, hpStream_t stream);
 
+/* The heads' weight gradient AND its torch.optim.Adam update in one pass (no counterpart in the reference: PyTorch
+ * materialises the 156 MB gradient and the optimiser re-reads it): rows [r0, r0+rows) of the (theta_ld x 2048) heads matrix,
+ *   g = dtheta_all[:, r0:r0+rows]^T . t5_all (Kc clouds);  W_rows, m_rows (exp_avg), v_rows (exp_avg_sq) <- Adam(g), in place;
+ * g is never written (6 x 156 MB of traffic instead of 8 x).  Pointers address row r0; 16-byte aligned; wd = 0. */
+int hp_hypernet_heads_dw_adam(int Kc, int rows, int r0, const float* dtheta_all, int theta_ld, const float* t5_all,
+                              float* W_rows, float* m_rows, float* v_rows, float lr, float beta1, float beta2, float eps,
+                              int step, hpStream_t stream);
+
 /* The B per-cloud TargetNetworks of one step at once (model/full_model.py:70-74, model/target_network.py:6-45).
  * theta (B,theta_ld): [W1 b1 | W2 b2 | ... | Wout bout] per cloud; pts (B,N,3) -> y (B,N,3) (rec[b] = y[b]^T).
  * acts: hidden activations kept for the backward (hp_target_saved_floats floats). */

@@ -190,3 +190,28 @@ def test_bench_chamfer_stress_workload_line():
     assert abs(line["value"] - 2 * 4 * 8192 * 8192 / (line["ms_per_step"] * 1e-3)) <= 1e-3 * line["value"]
     rf = line["roofline"]
     assert rf["bound"] == "valu" and 0 < rf["frac"] < 1 and rf["flops_per_launch"] == 8.0 * 2 * 4 * 8192 * 8192
+
+
+def test_fused_heads_dw_adam_equals_dw_then_adam():
+    """hp_hypernet_heads_dw_adam (gradient tile in registers -> Adam in place) against the two-pass form it replaces:
+    hp_hypernet_heads_dw_rows into a gradient buffer, then hp_adam_step over it.  Row slices as the ranks own them."""
+    import ctypes
+    from hyperpocket_amd import ops
+    from hyperpocket_amd._lib import call, current_stream, load_library
+    lib = load_library()
+    lib.hp_hypernet_heads_dw_workspace_floats.restype = ctypes.c_long
+    g = torch.Generator().manual_seed(5)
+    for kc, r0, rows, step in ((64, 0, 19011, 1), (128, 2377 * 5, 2377, 7), (6, 19000, 11, 3)):
+        dth = (torch.randn(kc, 19011, generator=g) * 0.1).cuda()
+        t5 = torch.randn(kc, 2048, generator=g).cuda()
+        w = torch.randn(rows, 2048, generator=g).cuda()
+        m = (torch.randn(rows, 2048, generator=g) * 0.01).cuda()
+        v = (torch.rand(rows, 2048, generator=g) * 1e-3).cuda()
+        w2, m2, v2 = w.clone(), m.clone(), v.clone()
+        grad = torch.empty(rows, 2048, device="cuda")
+        ws = torch.empty(lib.hp_hypernet_heads_dw_workspace_floats(), device="cuda")
+        call("hp_hypernet_heads_dw_rows", kc, rows, r0, dth, 19011, t5, grad, ws, current_stream(w.device))
+        ops.adam_step(w2.view(-1), grad.view(-1), m2.view(-1), v2.view(-1), 1e-4, 0.9, 0.999, 1e-8, step)
+        call("hp_hypernet_heads_dw_adam", kc, rows, r0, dth, 19011, t5, w, m, v, 1e-4, 0.9, 0.999, 1e-8, step,
+             current_stream(w.device))
+        assert torch.equal(w, w2) and torch.equal(m, m2) and torch.equal(v, v2), (kc, r0, rows)

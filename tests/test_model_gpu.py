@@ -580,8 +580,11 @@ def test_train_engine_vs_reference_golden():
                 assert abs(p.double().norm().item() - want[1]) <= ptol * want[1] + 1e-9, (s, k)
         assert eng.flat.is_intact()
         # gradients were written straight into the flat buffer (no copies): p.grad aliases it
-        p = dict(model.named_parameters())["hyper_network.output.3.weight"]
-        assert p.grad is not None and p.grad.data_ptr() == eng.flat.grad_of("hyper_network.output.3.weight").data_ptr()
+        p = dict(model.named_parameters())["hyper_network.model.8.weight"]
+        assert p.grad is not None and p.grad.data_ptr() == eng.flat.grad_of("hyper_network.model.8.weight").data_ptr()
+        # ... except the heads' weights: on one GPU their gradient is consumed tile by tile by the fused dW + Adam
+        # kernel and never stored
+        assert eng.fused is not None and dict(model.named_parameters())["hyper_network.output.3.weight"].grad is None
     finally:
         ops.clear_grad_views()
 
