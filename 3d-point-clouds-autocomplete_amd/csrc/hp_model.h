@@ -50,5 +50,5 @@ typedef struct HpHyperGrads {
 /* hypernet.hip (internal): fragment-direct heads kernels */
 bool hp_heads_dw_fast_ok(int cols, const float* t5, const float* out);
 int hp_heads_dw_launch(int Kc, int rows, int r0, const float* dtheta, int theta_ld, const float* t5, int cols, float* dW,
-                       hipStream_t stream);
+                       float* db, hipStream_t stream);
 #endif

@@ -12,6 +12,13 @@
 //    ADAM = false stores the gradient (one 156 MB write).  ADAM = true never materialises it: the epilogue reads
 //    W / exp_avg / exp_avg_sq at the same coordinates, applies torch.optim.Adam's update (core/main.py:62-66) and
 //    writes them back — 6 x 156 MB instead of the 8 x 156 MB of "write dW, then run Adam over it", and one launch.
+//    The bias gradient (column sums of d theta) rides on the A operand.
+//
+// Tried in the same style and NOT kept (measured, B=64): fragment-direct kernels for theta = t5 W^T (K-contiguous W: a
+// lane per row of W reads 32-byte pieces at an 8 KB stride — 277 us against the tiled GEMM's 70 us, DRAM pages thrash)
+// and for d t5 = d theta W (248 vs 78 us), and for the trunk's M = 64 layers (few waves with long dependent load chains:
+// 119 us forward against ~100 us).  Operands whose contiguous direction is the contraction need the LDS transpose of
+// gemm.hip; only dW — both operands contiguous along the lanes — streams well without it.
 #include "hp_common.h"
 #include "hp_model.h"
 #include <cmath>
@@ -36,6 +43,7 @@ struct HeadsDw {
     const float* t5;       // (Kc, cols)
     float* dW;             // ADAM = false: (rows, cols) output
     AdamArgs ad;           // ADAM = true: rows of W / exp_avg / exp_avg_sq, same (rows, cols) indexing
+    float* db;             // or NULL: db[r] = sum_k dtheta[k][r0 + r]  (bias gradient)
     int Kc, rows, r0, theta_ld, cols;
 };
 
@@ -51,6 +59,7 @@ __global__ __launch_bounds__(kHdThreads) __attribute__((amdgpu_waves_per_eu(4, 4
     const float* ap = a.dtheta + a.r0 + row0 + i;             // + k * theta_ld
     const float* bp = a.t5 + c0 + 4 * i;                      // + k * cols
     const int steps = (a.Kc + 1) >> 1;
+    float asum = 0.f;
     f32x16 acc[4] = {};
     float av[kPref];
     float4 bv[kPref];
@@ -68,11 +77,16 @@ __global__ __launch_bounds__(kHdThreads) __attribute__((amdgpu_waves_per_eu(4, 4
             const float x = av[u];
             const float4 y = bv[u];
             load(s0 + u + kPref, av[u], bv[u]);               // past the end: k >= Kc loads nothing
+            asum += x;
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y.x, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y.y, acc[1], 0, 0, 0);
             acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y.z, acc[2], 0, 0, 0);
             acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y.w, acc[3], 0, 0, 0);
         }
+    }
+    if (a.db && c0 == 0) {                                    // even clouds in lanes 0-31, odd clouds in lanes 32-63
+        const float other = __shfl_xor(asum, 32, 64);
+        if (h == 0 && row_ok) a.db[row0 + i] = asum + other;
     }
     // C layout of 32x32: lane (i, h), register e -> row (e&3) + 8*(e>>2) + 4*h, column i of the tile; tile t's column i
     // is the real column c0 + 4*i + t: the lane holds columns c0+4i .. c0+4i+3 of 16 rows.
@@ -135,8 +149,8 @@ bool hp_heads_dw_fast_ok(int cols, const float* t5, const float* out) {
 
 // dW_rows (rows x cols) = dtheta[:, r0:r0+rows]^T . t5     (internal: model.hip's hp_hypernet_backward / _heads_dw_rows)
 int hp_heads_dw_launch(int Kc, int rows, int r0, const float* dtheta, int theta_ld, const float* t5, int cols, float* dW,
-                       hipStream_t stream) {
-    HeadsDw a{dtheta, t5, dW, {}, Kc, rows, r0, theta_ld, cols};
+                       float* db, hipStream_t stream) {
+    HeadsDw a{dtheta, t5, dW, {}, db, Kc, rows, r0, theta_ld, cols};
     const dim3 grid((cols / kUnitCols + 3) / 4, (rows + kUnitRows - 1) / kUnitRows);
     hipLaunchKernelGGL(heads_dw_kernel<false>, grid, dim3(kHdThreads), 0, stream, a);
     return (int)hipGetLastError();
@@ -155,7 +169,7 @@ HP_API int hp_hypernet_heads_dw_adam(int Kc, int rows, int r0, const float* dthe
                  aligned16(m_rows) && aligned16(v_rows));
     const double bc1 = 1.0 - std::pow((double)beta1, step), bc2 = 1.0 - std::pow((double)beta2, step);
     HeadsDw a{dtheta_all, t5_all, nullptr, {W_rows, m_rows, v_rows, beta1, beta2, eps, (float)((double)lr / bc1),
-              (float)(1.0 / std::sqrt(bc2))}, Kc, rows, r0, theta_ld, 2048};
+              (float)(1.0 / std::sqrt(bc2))}, nullptr, Kc, rows, r0, theta_ld, 2048};
     const dim3 grid((2048 / kUnitCols + 3) / 4, (rows + kUnitRows - 1) / kUnitRows);
     hipLaunchKernelGGL(heads_dw_kernel<true>, grid, dim3(kHdThreads), 0, stream, a);
     HP_RETURN_LAST_ERROR();

@@ -729,8 +729,7 @@ HP_API int hp_hypernet_backward(int B, int in_size, const float* latent, const H
                        (skip_dw || heads_contiguous(gr->head_w, gr->head_b, w->head_out, w->n_heads));
     if (fused) {
         if (!skip_dw && hp_heads_dw_fast_ok(2048, act[4], gr->head_w[0])) {
-            TRY(hp_heads_dw_launch(B, total, 0, grad_theta, theta_ld, act[4], 2048, gr->head_w[0], stream));   // hypernet.hip
-            if (gr->head_b[0]) TRY(op.colsum(grad_theta, 0, theta_ld, B, total, 1, gr->head_b[0], 0));
+            TRY(hp_heads_dw_launch(B, total, 0, grad_theta, theta_ld, act[4], 2048, gr->head_w[0], gr->head_b[0], stream));   // hypernet.hip
         } else if (!skip_dw)
             TRY(op.lin_dw(grad_theta, 0, theta_ld, act[4], 0, 2048, gr->head_w[0], 0, B, total, 2048, 1, gr->head_b[0]));
         else if (gr->head_b[0])
@@ -772,7 +771,8 @@ HP_API int hp_hypernet_heads_dw_rows(int Kc, int rows, int r0, const float* dthe
     HP_CHECK_ARG(Kc > 0 && rows >= 0 && r0 >= 0 && r0 + rows <= theta_ld && dtheta_all && t5_all && ws);
     if (rows == 0) return 0;
     HP_CHECK_ARG(dW_rows);
-    if (hp_heads_dw_fast_ok(2048, t5_all, dW_rows)) return hp_heads_dw_launch(Kc, rows, r0, dtheta_all, theta_ld, t5_all, 2048, dW_rows, stream);
+    if (hp_heads_dw_fast_ok(2048, t5_all, dW_rows))
+        return hp_heads_dw_launch(Kc, rows, r0, dtheta_all, theta_ld, t5_all, 2048, dW_rows, nullptr, stream);
     Op op{stream, ws};
     TRY(op.lin_dw(dtheta_all + r0, 0, theta_ld, t5_all, 0, 2048, dW_rows, 0, Kc, rows, 2048, 1));
     HP_RETURN_LAST_ERROR();
