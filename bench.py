@@ -93,7 +93,7 @@ def roofline_dominant_kernel(batch, n_half):
     that runs the encoder's wide layers (M = B*1024 points).  One launch = layer 5 of one encoder:
     C(M x 512) = A(M x 512) W(512 x 512)^T + b.  Algorithmic flops = 2*M*512*512 (868 736 FLOP/point
     of which layer 5 is 2*512*512).  `traffic` (HBM bytes per launch) comes from the PMC passes recorded in
-    profiles/r01_pmc_gemm_conv5.json (FETCH_SIZE x2 correction + WRITE_SIZE), measured at B=64."""
+    profiles/r02_pmc_gemm_conv5.json (FETCH_SIZE x2 correction + WRITE_SIZE), measured at B=64."""
     from hyperpocket_amd.ops import gemm
     m = batch * n_half
     a = torch.randn(m, 512, device="cuda")
@@ -107,7 +107,7 @@ def roofline_dominant_kernel(batch, n_half):
     flops = 2.0 * m * 512 * 512
     achieved = flops / (ms * 1e-3) / 1e12
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm_conv5.json")
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_gemm_conv5.json")
     if os.path.exists(pmc) and batch == 64 and n_half == 1024:
         traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
     return {"bound": "mfma", "kernel": "gemm_kernel<128,128,4,2,16,4> (encoder conv5: M=B*1024, N=K=512, fp32 MFMA 32x32x2)",

@@ -1,59 +1,123 @@
 #!/usr/bin/env python3
-"""gpurun_out/final (tools/final_measure.sh) -> the summaries committed under profiles/."""
+"""gpurun_out/final (tools/final_measure.sh) -> the round-2 summaries committed under profiles/."""
 import csv, glob, json, os, shutil, subprocess, sys
 from collections import defaultdict
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 F = os.path.join(R, "gpurun_out", "final")
 P = os.path.join(R, "profiles")
 py = sys.executable
+RD = "r02"
 
 
-def counters(d, kernel_substr):
+def per_kernel(d):
+    """{kernel: ({counter: per-dispatch average}, dispatches, avg_us)} of one --pmc pass."""
     f = glob.glob(os.path.join(F, d, "**", "*_counter_collection.csv"), recursive=True)[0]
-    acc, disp = defaultdict(float), set()
+    acc, disp, dur = defaultdict(lambda: defaultdict(float)), defaultdict(set), defaultdict(float)
     for r in csv.DictReader(open(f)):
-        if kernel_substr in r["Kernel_Name"]:
-            acc[r["Counter_Name"]] += float(r["Counter_Value"])
-            disp.add(r["Dispatch_Id"])
-    return {k: v / len(disp) for k, v in acc.items()}, len(disp)
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "")
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Dispatch_Id"] not in disp[k]:
+            disp[k].add(r["Dispatch_Id"])
+            dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    return {k: ({c: v / len(disp[k]) for c, v in acc[k].items()}, len(disp[k]), dur[k] / len(disp[k])) for k in acc}
 
 
-shutil.copy(os.path.join(F, "bench_n1.json"), os.path.join(P, "r01_bench_n1.json"))
-shutil.copy(os.path.join(F, "bench_chamfer.json"), os.path.join(P, "r01_bench_n1_chamfer_only.json"))
-shutil.copy(os.path.join(F, "roofline_events.json"), os.path.join(P, "r01_roofline_hip_events.txt"))
-subprocess.check_call([py, os.path.join(R, "tools", "summarize_profile.py"), os.path.join(F, "step"),
-                       os.path.join(P, "r01_step_kernel_stats_final.md"),
-                       "Round 1 — full step: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-extras "
+def one(d, substr):
+    ks = per_kernel(d)
+    k = [k for k in ks if substr in k]
+    assert len(k) == 1, (d, substr, list(ks))
+    return ks[k[0]]
+
+
+for src, dst in (("bench_n1.json", "bench_n1.json"), ("bench_chamfer.json", "bench_n1_chamfer_only.json"),
+                 ("bench_stress.json", "bench_chamfer_stress_n8192.json"), ("roofline_events.json", "roofline_hip_events.txt")):
+    shutil.copy(os.path.join(F, src), os.path.join(P, f"{RD}_{dst}"))
+summ = os.path.join(R, "tools", "summarize_profile.py")
+subprocess.check_call([py, summ, os.path.join(F, "step"), os.path.join(P, f"{RD}_step_kernel_stats.md"),
+                       "Round 2 — full step: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-extras "
                        "--no-cpu-baseline (B=64, Chamfer+EMD; 7 engine steps, nothing else in the trace)", "7"])
-subprocess.check_call([py, os.path.join(R, "tools", "summarize_profile.py"), os.path.join(F, "roof"),
-                       os.path.join(P, "r01_roofline_kernel_stats.md"),
-                       "Round 1 — roofline launch alone: rocprofv3 --kernel-trace --stats -- python3 bench.py --roofline-only "
+subprocess.check_call([py, summ, os.path.join(F, "roof"), os.path.join(P, f"{RD}_roofline_kernel_stats.md"),
+                       "Round 2 — roofline launch alone: rocprofv3 --kernel-trace --stats -- python3 bench.py --roofline-only "
                        "(encoder conv5: M=65536, N=K=512; 200 warm-up + 100 timed launches, back to back)", "1"])
-subprocess.check_call([py, os.path.join(R, "tools", "pmc_summary.py"), os.path.join(P, "r01_pmc_step_kernels.md"),
-                       "Round 1 — PMC view of every kernel of the step (bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline)",
+subprocess.check_call([py, summ, os.path.join(F, "stress"), os.path.join(P, f"{RD}_chamfer_n8192_kernel_stats.md"),
+                       "Round 2 — BASELINE configs[4] per-GPU shape: rocprofv3 --kernel-trace --stats -- python3 bench.py --workload "
+                       "chamfer-stress --steps 5 --warmup 2 --no-extras (B=64, N=8192, Chamfer forward+backward; 7 steps)", "7"])
+pm = os.path.join(R, "tools", "pmc_summary.py")
+subprocess.check_call([py, pm, os.path.join(P, f"{RD}_pmc_step_kernels.md"),
+                       "Round 2 — PMC view of every kernel of the step (bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline)",
                        os.path.join(F, "step_pmc_FETCH_SIZE"), os.path.join(F, "step_pmc_WRITE_SIZE"), os.path.join(F, "step_pmc_BUSY")])
+subprocess.check_call([py, pm, os.path.join(P, f"{RD}_pmc_chamfer_n8192.md"),
+                       "Round 2 — PMC view of the Chamfer stress kernels (bench.py --workload chamfer-stress, B=64, N=8192)",
+                       os.path.join(F, "stress_pmc_FETCH_SIZE"), os.path.join(F, "stress_pmc_WRITE_SIZE"), os.path.join(F, "stress_pmc_BUSY")])
+
+# ---- dominant GEMM (roofline.traffic)
 k = "gemm_kernel<128, 128, 4, 2, 16, 4>"
-fe, n = counters("roof_pmc_FETCH_SIZE", k)
-wr, _ = counters("roof_pmc_WRITE_SIZE", k)
-bu, _ = counters("roof_pmc_BUSY", k)
+fe, n, _ = one("roof_pmc_FETCH_SIZE", k)
+wr, _, _ = one("roof_pmc_WRITE_SIZE", k)
+bu, _, us = one("roof_pmc_BUSY", k)
 rd = fe["FETCH_SIZE"] * 1024 * 2
 out = {
     "kernel": "gemm_kernel<128,128,4,2,16,4> (fp32 MFMA 32x32x2, encoder conv5 shape M=65536 N=512 K=512, plain C store)",
     "command": "rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python3 bench.py --roofline-only   (one pass per "
-               "counter group: FETCH_SIZE | WRITE_SIZE | GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU; tools/final_measure.sh)",
-    "launches_averaged": n,
-    "FETCH_SIZE_KB_raw": round(fe["FETCH_SIZE"], 1),
+               "counter group: FETCH_SIZE | WRITE_SIZE | GRBM_GUI_ACTIVE SQ_*; tools/final_measure.sh)",
+    "launches_averaged": n, "FETCH_SIZE_KB_raw": round(fe["FETCH_SIZE"], 1),
     "FETCH_SIZE_correction": "x2 (gfx950 counts 128-B requests at 64 B: MI355X_MICROARCH.md §HBM)",
-    "WRITE_SIZE_KB": round(wr["WRITE_SIZE"], 1),
-    "hbm_read_bytes_corrected": int(rd),
-    "hbm_write_bytes": int(wr["WRITE_SIZE"] * 1024),
-    "hbm_bytes_per_launch": int(rd + wr["WRITE_SIZE"] * 1024),
+    "WRITE_SIZE_KB": round(wr["WRITE_SIZE"], 1), "hbm_read_bytes_corrected": int(rd),
+    "hbm_write_bytes": int(wr["WRITE_SIZE"] * 1024), "hbm_bytes_per_launch": int(rd + wr["WRITE_SIZE"] * 1024),
     "algorithmic_bytes_per_launch": (2 * 65536 * 512 + 512 * 512 + 512) * 4,
-    "GRBM_GUI_ACTIVE_sum_over_8_xcd": bu["GRBM_GUI_ACTIVE"],
-    "SQ_VALU_MFMA_BUSY_CYCLES": bu["SQ_VALU_MFMA_BUSY_CYCLES"],
+    "GRBM_GUI_ACTIVE_sum_over_8_xcd": bu["GRBM_GUI_ACTIVE"], "SQ_VALU_MFMA_BUSY_CYCLES": bu["SQ_VALU_MFMA_BUSY_CYCLES"],
     "mfma_pipe_busy_frac": round(bu["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * bu["GRBM_GUI_ACTIVE"] / 8), 4),
-    "SQ_ACTIVE_INST_VALU": bu["SQ_ACTIVE_INST_VALU"],
+    "clock_GHz_in_profiled_pass": round(bu["GRBM_GUI_ACTIVE"] / 8 / (us * 1e-6) / 1e9, 3),
     "note": "profiled passes run at a lower clock than un-profiled ones; compare fractions, not times",
 }
-json.dump(out, open(os.path.join(P, "r01_pmc_gemm_conv5.json"), "w"), indent=1)
-print(json.dumps(out, indent=1))
+json.dump(out, open(os.path.join(P, f"{RD}_pmc_gemm_conv5.json"), "w"), indent=1)
+
+# ---- Chamfer stress kernel (roofline.traffic of --workload chamfer-stress)
+k = "nn_distance_kernel<4, true>"
+fe, n, _ = one("stress_pmc_FETCH_SIZE", k)
+wr, _, _ = one("stress_pmc_WRITE_SIZE", k)
+bu, _, us = one("stress_pmc_BUSY", k)
+rd = fe["FETCH_SIZE"] * 1024 * 2
+sim = 1024 * bu["GRBM_GUI_ACTIVE"] / 8
+out = {
+    "kernel": "nn_distance_kernel<4,true> (both directed passes of the Chamfer forward), B=64, N=8192", "batch": 64, "n": 8192,
+    "launches_averaged": n, "avg_us_profiled": round(us, 1),
+    "hbm_read_bytes_corrected": int(rd), "hbm_write_bytes": int(wr["WRITE_SIZE"] * 1024),
+    "hbm_bytes_per_launch": int(rd + wr["WRITE_SIZE"] * 1024), "algorithmic_bytes_per_launch": 64 * (2 * 8192 * 12 + 2 * 8192 * 8),
+    "hbm_GBps": round((rd + wr["WRITE_SIZE"] * 1024) / (us * 1e-6) / 1e9, 1),
+    "SQ_INSTS_VALU": bu["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU": bu["SQ_ACTIVE_INST_VALU"],
+    "valu_issue_busy_frac": round(bu["SQ_ACTIVE_INST_VALU"] * 4 / sim, 4),
+    "clock_GHz_in_profiled_pass": round(bu["GRBM_GUI_ACTIVE"] / 8 / (us * 1e-6) / 1e9, 3),
+    "valu_instructions_per_point_pair": round(bu["SQ_INSTS_VALU"] * 64 / (2.0 * 64 * 8192 * 8192), 3),
+    "note": "VALU issue busy = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE/8): the kernel is bound by vector "
+            "issue at the clock the chip holds under this load, not by HBM",
+}
+json.dump(out, open(os.path.join(P, f"{RD}_pmc_chamfer_n8192.json"), "w"), indent=1)
+
+# ---- EMD family: HBM bytes per hp_emd_forward call + measured VALU issue cycles against the model
+fes, wrs, bus = per_kernel("step_pmc_FETCH_SIZE"), per_kernel("step_pmc_WRITE_SIZE"), per_kernel("step_pmc_BUSY")
+steps = 4
+tot_bytes = tot_valu = tot_us = tot_gui = 0.0
+rows = []
+for kname in sorted(k for k in bus if k.startswith("void emd_") or k.startswith("emd_")):
+    c, n, us = bus[kname]
+    per_step = n / steps
+    b = (fes[kname][0]["FETCH_SIZE"] * 2048 + wrs[kname][0]["WRITE_SIZE"] * 1024) * per_step
+    tot_bytes += b
+    tot_valu += c["SQ_ACTIVE_INST_VALU"] * 4 * per_step
+    tot_us += us * per_step
+    tot_gui += c["GRBM_GUI_ACTIVE"] / 8 * per_step
+    rows.append({"kernel": kname, "launches_per_call": per_step, "avg_us_profiled": round(us, 1),
+                 "valu_issue_busy_frac": round(c["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * c["GRBM_GUI_ACTIVE"] / 8), 4),
+                 "hbm_MB_per_launch": round((fes[kname][0]["FETCH_SIZE"] * 2048 + wrs[kname][0]["WRITE_SIZE"] * 1024) / 1e6, 2)})
+mp = os.path.join(P, f"{RD}_emd_issue_model.json")
+model = json.load(open(mp))
+model["hbm_bytes_per_call"] = int(tot_bytes)
+model["pmc"] = {"command": "rocprofv3 --kernel-trace --pmc ... -- python3 bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline "
+                           "(tools/final_measure.sh); per hp_emd_forward call = per step",
+                "SQ_ACTIVE_INST_VALU_x4_cycles_per_call": int(tot_valu),
+                "model_over_measured_valu_cycles": round(model["issue_cycles_per_call"] / tot_valu, 4),
+                "valu_issue_busy_frac_of_kernel_time": round(tot_valu / (1024 * tot_gui), 4),
+                "kernel_time_us_per_call_profiled": round(tot_us, 1), "kernels": rows}
+json.dump(model, open(mp, "w"), indent=1)
+print(json.dumps(model["pmc"], indent=1)[:1500])
