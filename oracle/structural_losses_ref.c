@@ -14,8 +14,11 @@
  *       no tests or golden vectors for them and its CUDA sources cannot be built in
  *       this image (no nvcc, ATen CUDA headers).  The restatement follows the scalar
  *       spec the reference itself carries in comments (approxmatch.cu:94-107,
- *       143-159, 195-209) and is checked through analytic properties only
- *       (mass conservation, permutation equivariance, finite differences).
+ *       143-159, 195-209) and is checked through analytic properties (mass conservation,
+ *       permutation equivariance, finite differences) and BOUNDED against exact arithmetic:
+ *       ref_approxmatch_f64 evaluates the same algorithm in fp64, ref_approxmatch_ex under
+ *       every fma contraction nvcc may have applied; all agree on the cost to < 4e-7
+ *       (tests/test_oracle_golden.py).
  *
  * Arithmetic notes
  *   - squared distances are evaluated as the fmaf chain nvcc's default -fmad=true
@@ -25,10 +28,11 @@
  *   - __expf(x) (approxmatch.cu:86,131,185) is CUDA's fast exponential, defined as
  *     exp2(x * log2(e)) evaluated in fp32 (ex2.approx of the rounded product).  It is
  *     restated as exp2f(x * 1.4426950408889634f): the rounding of the product is part
- *     of the reference's arithmetic and the auction amplifies it (replacing it by a
- *     correctly rounded expf moves single match entries by up to 1.5e-3 and the cost by
- *     3e-5 relative, measured here).  The HIP kernels evaluate the same product and use
- *     the hardware v_exp_f32 (1 ulp), so EMD parity is a tolerance, not bit equality.
+ *     of the reference's arithmetic and the auction amplifies it in single match entries
+ *     (replacing it by a correctly rounded expf moves single entries by up to 3e-4; the
+ *     cost moves by <= 5e-7 relative — measured on five shapes up to 2x2048^2).  The HIP
+ *     kernels evaluate the same product and use the hardware v_exp_f32 (1 ulp), so EMD
+ *     parity is a tolerance, not bit equality.
  *   - per-thread sequential float accumulations keep the reference's order
  *     (ascending l / k); block tree reductions (approxmatch.cu:244-252,279-296) are
  *     restated as double accumulations.
