@@ -20,8 +20,9 @@
 //   * candidates are stored as PAIR records ([x0 x1 | y0 y1 | z0 z1 | w0 w1 ...]) so that the distance and
 //     weighting arithmetic of two candidates runs on packed fp32 VALU ops (v_pk_add/mul/fma_f32 with an SGPR
 //     pair as one operand) — the non-packed VALU rate is only half of the 157 TFLOP/s vector peak.  Each
-//     element still sees the reference's operation sequence (same fma chain, mul-then-add, ascending
-//     candidate order in the accumulators), so results are unchanged bit for bit.
+//     element still sees the reference's operation sequence as nvcc's default -fmad=true contracts it (distance
+//     fma chain, products entering the running sums through an fma, ascending candidate order in the
+//     accumulators): the C oracle's `contract` variant 3.
 //   * padding records carry zero weights and contribute exact zeros.
 #include "hp_common.h"
 #include <algorithm>
@@ -197,11 +198,13 @@ __global__ __launch_bounds__(kThreads) void emd_rows1_kernel(Ctx c, int lev1, fl
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const f2 d = sqdist2(PAIRC(lo, hi, u, 0) - px2[r], PAIRC(lo, hi, u, 1) - py2[r], PAIRC(lo, hi, u, 2) - pz2[r]);
+                // the running sums take their product through an fma — what nvcc's default -fmad=true makes of the
+                // reference's `w=...; suml+=w` (approxmatch.cu:86-87,185-189); the oracle's `contract` variant 3
                 if (DO3) {
-                    acc3[r] += (exp2_2(l3 * d) * rl2[r]) * PAIRC(lo, hi, u, 3);   // (e * ratioL[k]) * ratioR[l]
+                    acc3[r] = __builtin_elementwise_fma(exp2_2(l3 * d) * rl2[r], PAIRC(lo, hi, u, 3), acc3[r]);   // (e * ratioL[k]) * ratioR[l]
                 }
                 if (DO1) {
-                    acc1[r] += exp2_2(l1 * d) * f2{w[u * 2], w[u * 2 + 1]};   // e * remainR[l]
+                    acc1[r] = __builtin_elementwise_fma(exp2_2(l1 * d), f2{w[u * 2], w[u * 2 + 1]}, acc1[r]);   // e * remainR[l]
                 }
             }
         }
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(kThreads) void emd_rows2_kernel(Ctx c, int lev, flo
             for (int r = 0; r < R; ++r) {
                 // the reference evaluates (x2-x1) with x2 the set2 point in every phase (approxmatch.cu:85,131,185)
                 const f2 d = sqdist2(qx2[r] - PAIRC(lo, hi, u, 0), qy2[r] - PAIRC(lo, hi, u, 1), qz2[r] - PAIRC(lo, hi, u, 2));
-                acc2[r] += exp2_2(lv * d) * PAIRC(lo, hi, u, 3);
+                acc2[r] = __builtin_elementwise_fma(exp2_2(lv * d), PAIRC(lo, hi, u, 3), acc2[r]);   // approxmatch.cu:131-132 contracted
             }
         }
     };
@@ -714,13 +717,15 @@ __global__ __launch_bounds__(kThreads) void emd_plain_kernel(int n, int m, const
                 // (x2 - x1) with x2 the set2 point in every phase (approxmatch.cu:85,131,185)
                 const float d = kRowsL ? hp::sqdist(c.x - rx, c.y - ry, c.z - rz) : hp::sqdist(rx - c.x, ry - c.y, rz - c.z);
                 const float e = __builtin_amdgcn_exp2f(l2e * d);
+                // products enter the sums through an fma (nvcc's default -fmad=true contraction of the reference source;
+                // oracle `contract` variant 3), as in the packed-record sweeps
                 if (PHASE == 3) {
-                    const float w = (e * rl) * c.w;
+                    const float er = e * rl;
                     float* mp = mcol + (long)(c0 + t) * n;
-                    *mp = first ? w : *mp + w;        // level 0 writes (the reference's zero fill + first `+=`)
-                    sum += w;
+                    *mp = first ? er * c.w : __builtin_fmaf(er, c.w, *mp);   // level 0 writes (zero fill + first `+=`)
+                    sum = __builtin_fmaf(er, c.w, sum);
                 } else {
-                    sum += e * c.w;
+                    sum = __builtin_fmaf(e, c.w, sum);
                 }
             }
         }

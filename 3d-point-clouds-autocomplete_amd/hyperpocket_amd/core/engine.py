@@ -103,10 +103,15 @@ class FusedHeadsAdam:
     instead of the 8 x 156 MB of "write dW, then one Adam pass over it", and the step's last Adam pass shrinks to the
     17 MB of everything else.  Same object protocol as HeadsShard (ops.HEADS_DW_EXCHANGE)."""
 
-    def __init__(self, engine):
+    def __init__(self, engine, own_stream=True):
         h = engine.flat.heads
         self.engine, self.flat = engine, engine.flat
         self.lo, self.hi, self.rows, self.cols = h["lo"], h["hi"], h["rows"], h["cols"]
+        # The pass is an HBM stream (186 us at B=64); what follows it in the step — the encoders' backward — is ~70 small
+        # dependent launches that leave HBM idle.  On a stream of its own the two overlap; `join` orders it before the next
+        # reader of the heads' weights.
+        self.stream = torch.cuda.Stream(device=engine.flat.flat.device) if own_stream else None
+        self._keep = None
 
     accepts = HeadsShard.accepts
 
@@ -117,9 +122,21 @@ class FusedHeadsAdam:
         """Called by HyperNetFunction.backward AFTER hp_hypernet_backward has been enqueued (stream order: after d t5)."""
         e = self.engine
         n = self.rows * self.cols
-        call("hp_hypernet_heads_dw_adam", grad_theta.size(0), self.rows, 0, grad_theta, grad_theta.size(1), t5,
-             self.flat.flat[self.lo:self.lo + n], e.exp_avg[self.lo:self.lo + n], e.exp_avg_sq[self.lo:self.lo + n],
-             float(e.lr), float(e.betas[0]), float(e.betas[1]), float(e.eps), int(e._adam_step), current_stream(grad_theta.device))
+        dev = grad_theta.device
+        cur = torch.cuda.current_stream(dev)
+        st = self.stream if self.stream is not None else cur
+        if st is not cur:
+            st.wait_stream(cur)
+            self._keep = (grad_theta, t5)      # alive until join(): the side stream reads them
+        with torch.cuda.stream(st):
+            call("hp_hypernet_heads_dw_adam", grad_theta.size(0), self.rows, 0, grad_theta, grad_theta.size(1), t5,
+                 self.flat.flat[self.lo:self.lo + n], e.exp_avg[self.lo:self.lo + n], e.exp_avg_sq[self.lo:self.lo + n],
+                 float(e.lr), float(e.betas[0]), float(e.betas[1]), float(e.eps), int(e._adam_step), current_stream(dev))
+
+    def join(self):
+        if self.stream is not None and self._keep is not None:
+            torch.cuda.current_stream(self.flat.flat.device).wait_stream(self.stream)
+            self._keep = None
 
 
 class TrainEngine:
@@ -152,7 +169,8 @@ class TrainEngine:
         # stored: their .grad stays None)
         self.fused = None
         if not self.exchange and fuse_heads_adam and HeadsShard.usable(self.flat, 1):
-            self.fused = FusedHeadsAdam(self)
+            import os
+            self.fused = FusedHeadsAdam(self, own_stream=os.environ.get("HP_HEADS_ADAM_STREAM", "1") != "0")
         if self.exchange:
             # replicas start from rank 0's weights
             dist.broadcast(self.flat.flat, src=0, group=process_group)
@@ -205,6 +223,8 @@ class TrainEngine:
             # nothing to exchange: one pass over the flat buffer (minus the heads' weights when their update was fused
             # into the hypernetwork backward)
             self._adam_range(self.fused.hi if self.fused is not None else 0, self.flat.total)
+            if self.fused is not None:
+                self.fused.join()
             self._heads_pending = False
             return out
         if self.shard is not None:

@@ -123,9 +123,12 @@ static inline float pair_d2(const float *p, const float *q) {
  * per cloud (the reference indexes it by blockIdx.x, :35 — scratch, contents after the
  * call are the last state of whatever cloud that block processed; here: cloud i).
  *
- * `contract` selects which single-rounding contractions nvcc's default -fmad=true MAY have applied
- * to the reference's source (unknowable here: no nvcc, no reference vectors) — the restatement
- * proper is contract = 0 (every product rounded before its add, what the HIP kernels do):
+ * `contract` selects which single-rounding contractions nvcc's default -fmad=true applies to the
+ * reference's source (the reference's setup.py passes no flags; unverifiable here: no nvcc, no
+ * reference vectors).  contract = 0 is the literal source (every product rounded before its add);
+ * contract = 3 — products entering the running sums through an fma, bits 0 and 1 — is what the
+ * default contraction most plausibly yields and what the HIP kernels implement since round 2 (the
+ * per-entry parity tests use it; the cost gate is checked against both, they agree to 4e-7):
  *   bit 0: the phase-1/2 sums  `w=__expf(d)*buf; suml+=w`   -> fmaf(e, buf, suml)   (:86-87,:131-132)
  *   bit 1: phase 3             `match+=w; suml+=w`          -> fmaf(e*rl, rr, .)    (:185-187)
  *   bit 2: the phase-2 tail    `sumr+1e-9f`, `remainR-sumr` -> fmaf(sum, rr, 1e-9f), fmaf(-sum, rr, rr) (:137-140)

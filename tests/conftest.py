@@ -62,9 +62,13 @@ class OracleLib:
                                     self._p(gd2), self._p(i2), self._p(g1), self._p(g2))
         return g1, g2
 
-    def approxmatch(self, xyz1, xyz2, contract=0):
+    # which fma contractions of the reference source the HIP kernels implement (oracle/structural_losses_ref.c): nvcc's
+    # default -fmad=true applied to the phase sums and phase 3 — bits 0 and 1
+    KERNEL_CONTRACT = 3
+
+    def approxmatch(self, xyz1, xyz2, contract=KERNEL_CONTRACT):
         """contract: which fma contractions of the reference source to assume (oracle/structural_losses_ref.c);
-        0 = the restatement proper."""
+        0 = the literal source (every product rounded before its add), 3 = nvcc's default contraction (the kernels')."""
         xyz1, xyz2 = np.ascontiguousarray(xyz1, np.float32), np.ascontiguousarray(xyz2, np.float32)
         b, n, m = xyz1.shape[0], xyz1.shape[1], xyz2.shape[1]
         match = np.empty((b, m, n), np.float32)

