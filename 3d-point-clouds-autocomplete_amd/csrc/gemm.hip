@@ -31,8 +31,9 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// BK (k-tile depth) is a template parameter: 32 for the big 128x128 tile (half the barriers per MFMA, full
-// 128-byte lines per staged row), 16 for the small tiles.  LDS rows are padded by 4 floats (BK+4): 16-byte
+// BK (k-tile depth) is a template parameter: 16 for the 8-wave 128x128, the 64x128 and the 128x32 tiles (the
+// instantiations at the bottom of this file; BK=32/64 on the 128x128 tile measured no faster), 32 for the 64x64 tile
+// (half the barriers per MFMA, full 128-byte lines per staged row).  LDS rows are padded by 4 floats (BK+4): 16-byte
 // aligned and conflict-free for the ds_read_b128 fragment reads at both depths.
 constexpr int kMaxBK = 32;
 
