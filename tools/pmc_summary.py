@@ -6,7 +6,7 @@ from collections import defaultdict
 
 
 def load(d):
-    f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0]
+    f = max(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
     acc = defaultdict(lambda: defaultdict(float))
     cnt = defaultdict(lambda: defaultdict(int))
     dur = defaultdict(float)

@@ -11,7 +11,7 @@ RD = "r02"
 
 def per_kernel(d):
     """{kernel: ({counter: per-dispatch average}, dispatches, avg_us)} of one --pmc pass."""
-    f = glob.glob(os.path.join(F, d, "**", "*_counter_collection.csv"), recursive=True)[0]
+    f = max(glob.glob(os.path.join(F, d, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
     acc, disp, dur = defaultdict(lambda: defaultdict(float)), defaultdict(set), defaultdict(float)
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].replace("(anonymous namespace)::", "")

@@ -8,7 +8,7 @@ import sys
 
 
 def main(src, dst, title, steps):
-    f = glob.glob(os.path.join(src, "**", "*_kernel_stats.csv"), recursive=True)[0]
+    f = max(glob.glob(os.path.join(src, "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     rows = list(csv.DictReader(open(f)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     with open(dst, "w") as o:
