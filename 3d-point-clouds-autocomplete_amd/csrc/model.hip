@@ -19,7 +19,9 @@
 #include "hp_common.h"
 #include "hp_gemm.h"
 #include "hp_model.h"
+#include "hp_skinny.h"
 #include <algorithm>
+#include <cstdlib>
 
 extern "C" int hp_gemm_f32(const HpGemmDesc* d, hipStream_t stream);
 extern "C" int hp_gemm_tile_rows(const HpGemmDesc* d);
@@ -660,6 +662,136 @@ bool heads_contiguous(P const* hw, P const* hb, const int* out, int n) {
         if (hw[h + 1] != hw[h] + (long)out[h] * 2048 || hb[h + 1] != hb[h] + out[h]) return false;
     return n > 0;
 }
+
+// ---- the trunk as skinny-M layer programs (skinny.hip): one persistent launch per direction --------------------
+int env_int(const char* name, int dflt) {
+    const char* e = std::getenv(name);
+    return e && *e ? std::atoi(e) : dflt;
+}
+// contraction ranges of a layer: a power of two, <= smax, each range at least 32 long, and no more tasks than CUs
+int sk_ranges(int contraction, int out_blocks, int smax) {
+    int s = 1;
+    while (2 * s <= smax && contraction / (2 * s) >= 32 && contraction % (2 * s) == 0 && out_blocks * 2 * s <= 256) s *= 2;
+    return s;
+}
+inline long up4(long v) { return (v + 3) / 4 * 4; }
+
+// model/hyper_network.py:16-30, 41 (self.model(x)).  slabs: kSplitWs floats.  Returns -2 when the shapes do not fit.
+int trunk_forward_skinny(int B, int in_size, const float* latent, const HpHyperWeights* w, float* t, float* slabs,
+                         hipStream_t stream) {
+    static const int smax = env_int("HP_SK_SF", 4);
+    if (B > 64 || in_size % 32) return -2;
+    HpSkProgram pr{};
+    HpSkSrc src{};
+    src.p = latent; src.S = 1; src.ld = in_size;
+    float* tl = t;
+    float* sl = slabs;
+    int kin = in_size;
+    for (int l = 0; l < 5; ++l) {
+        const int N = kTrunk[l];
+        const int S = sk_ranges(kin, N / 32, smax);
+        HpSkOp& op = pr.op[pr.nops++];
+        op.type = HP_SK_F; op.phase = l;
+        op.a = src;
+        op.w = w->trunk_w[l]; op.w_ld = kin;
+        op.M = B; op.N = N; op.K = kin; op.CL = kin / S;
+        op.out_ld = N;
+        HpSkSrc next{};
+        next.ld = N;
+        if (S == 1) {
+            op.out = tl; op.out_bias = w->trunk_b[l]; op.out_relu = l < 4;
+            next.p = tl; next.S = 1;
+        } else {
+            op.out = sl; op.out_slab = 64L * N;
+            next.p = sl; next.slab = 64L * N; next.S = S; next.bias = w->trunk_b[l]; next.relu = l < 4;
+            next.mat = tl; next.ldmat = N;
+            sl += (long)S * 64 * N;
+            if (sl - slabs > kSplitWs) return -2;
+        }
+        src = next;
+        kin = N;
+        tl += (long)B * N;
+    }
+    if (src.S > 1) {   // t5 = sum of the last layer's slabs + bias
+        HpSkOp& op = pr.op[pr.nops++];
+        op.type = HP_SK_FIN; op.phase = 5;
+        op.out = src.mat; op.out_ld = src.ldmat;
+        src.mat = nullptr;
+        op.a = src;
+        op.M = B; op.N = 2048; op.K = 1;
+    }
+    return hp_skinny_run(&pr, stream);
+}
+
+// autograd of the trunk: dt[4] (B x 2048) is given; writes every trunk dW/db, dt[0..3] and grad_latent (or skips it)
+int trunk_backward_skinny(int B, int in_size, const float* latent, const HpHyperWeights* w, const float* const* act,
+                          float* const* dt, const HpHyperGrads* gr, float* grad_latent, float* slabs, hipStream_t stream) {
+    static const int smax = env_int("HP_SK_SX", 4);
+    if (B > 64 || in_size % 32) return -2;
+    HpSkProgram pr{};
+    HpSkSrc src{};
+    src.p = dt[4]; src.S = 1; src.ld = kTrunk[4];
+    float* sl = slabs;
+    int phase = 0;
+    auto dw_op = [&](int l) {   // dW_l = dt_l^T . (activation below), db_l = column sums of dt_l
+        HpSkOp& op = pr.op[pr.nops++];
+        op.type = HP_SK_W; op.phase = phase;
+        op.a.p = dt[l]; op.a.S = 1; op.a.ld = kTrunk[l];
+        op.w = l ? act[l - 1] : latent; op.w_ld = l ? kTrunk[l - 1] : in_size;
+        op.out = gr->trunk_w[l]; op.out_ld = op.w_ld; op.rsum = gr->trunk_b[l];
+        op.M = B; op.N = kTrunk[l]; op.K = op.w_ld;
+    };
+    for (int l = 4; l >= 0; --l, ++phase) {
+        const int N = kTrunk[l], K = l ? kTrunk[l - 1] : in_size;
+        if (l == 0 && !grad_latent) {   // only dt0 is still needed (by dW0)
+            HpSkOp& op = pr.op[pr.nops++];
+            op.type = HP_SK_FIN; op.phase = phase;
+            op.out = src.mat; op.out_ld = src.ldmat;
+            src.mat = nullptr;
+            op.a = src;
+            op.M = B; op.N = N; op.K = 1;
+        } else {
+            const int S = sk_ranges(N, K / 32, smax);
+            HpSkOp& op = pr.op[pr.nops++];
+            op.type = HP_SK_X; op.phase = phase;
+            op.a = src;
+            op.w = w->trunk_w[l]; op.w_ld = K;
+            op.M = B; op.N = N; op.K = K; op.CL = N / S;
+            op.out_ld = K;
+            HpSkSrc next{};
+            next.ld = K;
+            if (l == 0) {
+                if (S == 1) {
+                    op.out = grad_latent;
+                } else {
+                    op.out = sl; op.out_slab = 64L * K;
+                    next.p = sl; next.slab = 64L * K; next.S = S;
+                    sl += (long)S * 64 * K;
+                }
+            } else {
+                op.out = sl; op.out_slab = 64L * K;
+                next.p = sl; next.slab = 64L * K; next.S = S;
+                next.mask = act[l - 1]; next.ldm = K; next.mat = dt[l - 1]; next.ldmat = K;
+                sl += (long)S * 64 * K;
+            }
+            if (sl - slabs > kSplitWs) return -2;
+            src = next;
+        }
+        // the weight gradient of the layer whose dt was materialised by the PREVIOUS phase's readers (dt4 is given)
+        if (l == 4) dw_op(4);
+        else if (l <= 2) dw_op(l + 1);
+    }
+    // phase 5: grad_latent from its slabs; dW0 (dt0 was materialised in phase 4)
+    if (grad_latent && src.p && src.S > 1) {
+        HpSkOp& op = pr.op[pr.nops++];
+        op.type = HP_SK_FIN; op.phase = phase;
+        op.a = src;
+        op.out = grad_latent; op.out_ld = in_size;
+        op.M = B; op.N = in_size; op.K = 1;
+    }
+    dw_op(0);
+    return hp_skinny_run(&pr, stream);
+}
 }  // namespace
 
 // saved trunk activations + the split-K slab area the skinny (M = B) forward GEMMs use
@@ -674,11 +806,17 @@ HP_API int hp_hypernet_forward(int B, int in_size, const float* latent, const Hp
     const float* in = latent;
     int kin = in_size;
     float* tl = t;
-    for (int l = 0; l < 5; ++l) {
-        TRY(op.lin_fwd(in, 0, kin, w->trunk_w[l], 0, w->trunk_b[l], 0, tl, 0, kTrunk[l], B, kTrunk[l], kin, 1, l < 4));
-        in = tl;
-        kin = kTrunk[l];
-        tl += (long)B * kTrunk[l];
+    int sk = hp_skinny_enabled() ? trunk_forward_skinny(B, in_size, latent, w, t, op.splitws, stream) : -2;
+    if (sk != -2) {
+        TRY(sk);
+        in = t + (long)B * (64 + 128 + 512 + 1024);
+    } else {
+        for (int l = 0; l < 5; ++l) {
+            TRY(op.lin_fwd(in, 0, kin, w->trunk_w[l], 0, w->trunk_b[l], 0, tl, 0, kTrunk[l], B, kTrunk[l], kin, 1, l < 4));
+            in = tl;
+            kin = kTrunk[l];
+            tl += (long)B * kTrunk[l];
+        }
     }
     int total = 0;
     for (int hd = 0; hd < w->n_heads; ++hd) total += w->head_out[hd];
@@ -744,6 +882,10 @@ HP_API int hp_hypernet_backward(int B, int in_size, const float* latent, const H
         off += nh;
     }
     // trunk
+    {
+        const int sk = hp_skinny_enabled() ? trunk_backward_skinny(B, in_size, latent, w, act, dt, gr, grad_latent, p, stream) : -2;
+        if (sk != -2) return sk ? sk : (int)hipGetLastError();
+    }
     for (int l = 4; l >= 0; --l) {
         const float* below = l ? act[l - 1] : latent;
         const int kin = l ? kTrunk[l - 1] : in_size;

@@ -232,6 +232,12 @@ int hp_hypernet_heads_dw_adam(int Kc, int rows, int r0, const float* dtheta_all,
                               float* W_rows, float* m_rows, float* v_rows, float lr, float beta1, float beta2, float eps,
                               int step, hpStream_t stream);
 
+/* The M = B <= 64 chains (hypernetwork trunk, encoder fc/mu/std tail) run as ONE persistent launch per direction
+ * (csrc/skinny.hip: layers are phases separated by a grid-wide barrier) when their shapes allow, otherwise as tiled GEMM
+ * launches.  Diagnostic switch for parity tests: 0 forces the GEMM launches, 1 the layer programs, -1 the default
+ * (on; HP_SKINNY=0 in the environment turns it off).  Returns the previous setting.  No reference counterpart. */
+int hp_skinny_set_enabled(int on);
+
 /* The B per-cloud TargetNetworks of one step at once (model/full_model.py:70-74, model/target_network.py:6-45).
  * theta (B,theta_ld): [W1 b1 | W2 b2 | ... | Wout bout] per cloud; pts (B,N,3) -> y (B,N,3) (rec[b] = y[b]^T).
  * acts: hidden activations kept for the backward (hp_target_saved_floats floats). */

@@ -225,9 +225,21 @@ def test_encoder_backward_distinct_critical_points_equal_per_channel_rows():
             grad_close(grads[0][k], grads[2][k], tol=2e-5)
 
 
-def test_hypernet_forward_backward_vs_oracle(ref):
+@pytest.mark.parametrize("skinny,B", [(1, 7), (1, 64), (1, 33), (0, 7), (1, 70)])
+def test_hypernet_forward_backward_vs_oracle(ref, skinny, B):
+    """Both trunk paths against the oracle: the persistent layer program (csrc/skinny.hip, B <= 64; B = 70 falls back by
+    itself) and the tiled GEMM launches."""
+    from hyperpocket_amd import _lib
     from hyperpocket_amd.model.hyper_network import HyperNetwork
     from hyperpocket_amd.core.setup import weights_init
+    prev = _lib.load_library().hp_skinny_set_enabled(skinny)
+    try:
+        _hypernet_vs_oracle(ref, B, HyperNetwork, weights_init)
+    finally:
+        _lib.load_library().hp_skinny_set_enabled(prev)
+
+
+def _hypernet_vs_oracle(ref, B, HyperNetwork, weights_init):
     torch.manual_seed(4)
     cfg = {"use_bias": True, "relu_slope": 0.2, "input_size": 256, "target_network_layer_out_channels": [32, 64, 128, 64],
            "target_network_use_bias": True, "target_network_freeze_layers_learning": False}
@@ -239,14 +251,14 @@ def test_hypernet_forward_backward_vs_oracle(ref):
     P = {"hyper_network." + k: v.detach().clone().requires_grad_(True) for k, v in hn.state_dict().items()}
     hn = hn.cuda()
     g = torch.Generator().manual_seed(6)
-    lat = torch.randn(7, 256, generator=g)
+    lat = torch.randn(B, 256, generator=g)
     lat_d = lat.cuda().requires_grad_(True)
     lat_r = lat.clone().requires_grad_(True)
     theta = hn(lat_d)
     rtheta = ref.hypernet_forward(P, lat_r)
-    assert theta.shape == (7, 19011)
+    assert theta.shape == (B, 19011)
     close(theta, rtheta, rtol=1e-5, atol=1e-5)
-    w = torch.randn(7, 19011, generator=g)
+    w = torch.randn(B, 19011, generator=g)
     (theta * w.cuda()).sum().backward()
     (rtheta * w).sum().backward()
     grad_close(lat_d.grad, lat_r.grad)
