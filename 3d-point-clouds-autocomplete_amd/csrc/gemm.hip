@@ -26,6 +26,7 @@
 // tiles share an A or B panel in that XCD's L2).
 #include "hp_common.h"
 #include "hp_gemm.h"
+#include <cstdlib>
 
 namespace {
 
@@ -541,7 +542,8 @@ int launch_cfg(KParams& p, int batch, hipStream_t stream) {
     // 0 = i/j-contiguous.  The pairs the step produces are instantiated; any other falls back to loader 0, which is
     // correct for every layout.
     const int am = p.sAk == 1 ? (p.vecA ? 1 : 2) : 0, bm = p.sBk == 1 ? (p.vecB ? 1 : 2) : 0;
-#define HP_GEMM_LAUNCH(MODE_) hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, MODE_>), grid, block, 0, stream, p)
+    static const int pad_lds = [] { const char* e = getenv("HP_GEMM_PAD_LDS"); return e ? atoi(e) : 0; }();   // experiment: occupancy cap
+#define HP_GEMM_LAUNCH(MODE_) hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, MODE_>), grid, block, (BM >= 128 && BN >= 128) ? pad_lds : 0, stream, p)
     if (am == 1 && bm == 1) HP_GEMM_LAUNCH(4);
     else if (am == 1 && bm == 2) HP_GEMM_LAUNCH(7);
     else if (am == 2 && bm == 0) HP_GEMM_LAUNCH(2);

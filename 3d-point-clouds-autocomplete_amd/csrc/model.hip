@@ -443,6 +443,100 @@ long enc_bwd_ws(long B, long out) {
     return Rc * 4 + Rc * (64 + 128 + 256 + 512) * 2 + B * (2 * out + 4 * 512) + kSplitWs + 64 + (B * (4 * 512 + 4) + 16);
 }
 
+
+// ---- skinny-M layer programs (skinny.hip): shared helpers ---------------------------------------------------------
+int env_int(const char* name, int dflt) {
+    const char* e = std::getenv(name);
+    return e && *e ? std::atoi(e) : dflt;
+}
+// contraction ranges of a layer: a power of two, <= smax, each range at least 32 long, and no more tasks than CUs
+int sk_ranges(int contraction, int out_blocks, int smax) {
+    int s = 1;
+    while (2 * s <= smax && contraction / (2 * s) >= 32 && contraction % (2 * s) == 0 && out_blocks * 2 * s <= 256) s *= 2;
+    return s;
+}
+inline long up4(long v) { return (v + 3) / 4 * 4; }
+
+
+// model/encoder.py:46-53 after the max-pool: f = ReLU(fc g) ; mu = mu_layer f ; lv = std_layer f.  Two launches (the fc
+// layer in k-ranges whose slabs the mu/std tasks finish on load, writing f on the way) instead of 3 un-split GEMMs of
+// ~19 us each.  slabs: 4*64*512 floats.  Returns -2 when the shapes do not fit.
+int enc_tail_forward_skinny(int B, int out_size, const float* g, const HpEncoderWeights* w, int is_vae, float* f, float* mu,
+                            float* lv, float* slabs, hipStream_t stream) {
+    if (B > 64 || out_size % 32) return -2;
+    HpSkProgram pr{};
+    const int S = sk_ranges(512, 512 / 32, 4);
+    HpSkOp& fc = pr.op[pr.nops++];
+    fc.type = HP_SK_F; fc.phase = 0;
+    fc.a.p = g; fc.a.S = 1; fc.a.ld = 512;
+    fc.w = w->fc_w; fc.w_ld = 512;
+    fc.M = B; fc.N = 512; fc.K = 512; fc.CL = 512 / S;
+    fc.out = slabs; fc.out_slab = 64L * 512; fc.out_ld = 512;
+    if (S == 1) return -2;
+    HpSkSrc fsrc{};
+    fsrc.p = slabs; fsrc.slab = 64L * 512; fsrc.S = S; fsrc.ld = 512; fsrc.bias = w->fc_b; fsrc.relu = 1;
+    fsrc.mat = f; fsrc.ldmat = 512;
+    for (int hd = 0; hd < (is_vae ? 2 : 1); ++hd) {
+        HpSkOp& op = pr.op[pr.nops++];
+        op.type = HP_SK_F; op.phase = 1;
+        op.a = fsrc;
+        if (hd) op.a.mat = nullptr;          // f is written once, by the mu tasks
+        op.w = hd ? w->std_w : w->mu_w; op.w_ld = 512;
+        op.M = B; op.N = out_size; op.K = 512; op.CL = 512;
+        op.out = hd ? lv : mu; op.out_ld = out_size; op.out_bias = hd ? w->std_b : w->mu_b;
+    }
+    return hp_skinny_run(&pr, stream);
+}
+
+// the autograd of that tail: dmu (and dlv) -> d mu_w/b, d std_w/b, dfc = (dmu mu_w + dlv std_w) * (f > 0), d fc_w/b,
+// dg = dfc fc_w.  Three launches instead of 7-8.  slabs: 8*64*512 floats.
+int enc_tail_backward_skinny(int B, int out_size, const float* g, const float* f, const HpEncoderWeights* w, const float* dmu,
+                             const float* dlv, const HpEncoderGrads* gr, float* dfc, float* dg, float* slabs,
+                             hipStream_t stream) {
+    if (B > 64 || out_size % 32) return -2;
+    HpSkProgram pr{};
+    const int nh = dlv ? 2 : 1;
+    const int S = sk_ranges(out_size, 512 / 32, 4 / nh);      // the two heads' ranges land in ONE slab set (<= 4 slabs)
+    for (int hd = 0; hd < nh; ++hd) {
+        HpSkOp& op = pr.op[pr.nops++];
+        op.type = HP_SK_X; op.phase = 0;
+        op.a.p = hd ? dlv : dmu; op.a.S = 1; op.a.ld = out_size;
+        op.w = hd ? w->std_w : w->mu_w; op.w_ld = 512;
+        op.M = B; op.N = out_size; op.K = 512; op.CL = out_size / S;
+        op.out = slabs + (long)hd * S * 64 * 512; op.out_slab = 64L * 512; op.out_ld = 512;
+    }
+    if (nh * S == 1) return -2;                                // (a single range would apply no mask: not built)
+    for (int hd = 0; hd < nh; ++hd) {
+        HpSkOp& op = pr.op[pr.nops++];
+        op.type = HP_SK_W; op.phase = 0;
+        op.a.p = hd ? dlv : dmu; op.a.S = 1; op.a.ld = out_size;
+        op.w = f; op.w_ld = 512;
+        op.out = hd ? gr->std_w : gr->mu_w; op.out_ld = 512; op.rsum = hd ? gr->std_b : gr->mu_b;
+        op.M = B; op.N = out_size; op.K = 512;
+    }
+    float* s2 = slabs + (long)nh * S * 64 * 512;
+    const int S2 = sk_ranges(512, 512 / 32, 4);
+    if (S2 == 1) return -2;
+    HpSkOp& xf = pr.op[pr.nops++];
+    xf.type = HP_SK_X; xf.phase = 1;
+    xf.a.p = slabs; xf.a.slab = 64L * 512; xf.a.S = nh * S; xf.a.ld = 512; xf.a.mask = f; xf.a.ldm = 512;
+    xf.a.mat = dfc; xf.a.ldmat = 512;
+    xf.w = w->fc_w; xf.w_ld = 512;
+    xf.M = B; xf.N = 512; xf.K = 512; xf.CL = 512 / S2;
+    xf.out = s2; xf.out_slab = 64L * 512; xf.out_ld = 512;
+    HpSkOp& fin = pr.op[pr.nops++];
+    fin.type = HP_SK_FIN; fin.phase = 2;
+    fin.a.p = s2; fin.a.slab = 64L * 512; fin.a.S = S2; fin.a.ld = 512;
+    fin.out = dg; fin.out_ld = 512;
+    fin.M = B; fin.N = 512; fin.K = 1;
+    HpSkOp& wf = pr.op[pr.nops++];
+    wf.type = HP_SK_W; wf.phase = 2;
+    wf.a.p = dfc; wf.a.S = 1; wf.a.ld = 512;
+    wf.w = g; wf.w_ld = 512;
+    wf.out = gr->fc_w; wf.out_ld = 512; wf.rsum = gr->fc_b;
+    wf.M = B; wf.N = 512; wf.K = 512;
+    return hp_skinny_run(&pr, stream);
+}
 }  // namespace
 
 // =================================================================================================
@@ -483,20 +577,31 @@ HP_API int hp_encoder_forward(int B, int Np, const float* x, const HpEncoderWeig
     d5.flags = HP_GEMM_BIAS | HP_GEMM_COLMAX;
     d5.group_rows = Np;
     const int tr = hp_gemm_tile_rows(&d5);
+    float* tail_slabs = nullptr;
     if (tr > 0 && Np % tr == 0) {
         const long tiles = R / tr;
         d5.cmax = h[5];
         d5.cidx = reinterpret_cast<int*>(h[5] + tiles * 512);
+        if (R * 512 - up4(2 * tiles * 512) >= 4L * 64 * 512) tail_slabs = h[5] + up4(2 * tiles * 512);
         TRY(hp_gemm_f32(&d5, stream));
         hipLaunchKernelGGL(colmax_tiles_kernel, dim3(2, B), dim3(256), 0, stream, d5.cmax, d5.cidx, Np / tr, tr, 512, g, argidx);
     } else {
         TRY(op.lin_fwd(h[4], 0, 512, w->conv_w[4], 0, w->conv_b[4], 0, h[5], 0, 512, (int)R, 512, 512, 1, false));
         hipLaunchKernelGGL(colmax_kernel, dim3(512 / 64, B), dim3(256), 0, stream, h[5], Np, 512, g, argidx);
     }
-    TRY(op.lin_fwd(g, 0, 512, w->fc_w, 0, w->fc_b, 0, f, 0, 512, B, 512, 512, 1, true));
-    TRY(op.lin_fwd(f, 0, 512, w->mu_w, 0, w->mu_b, 0, mu, 0, out_size, B, out_size, 512, 1, false));
+    // the fc / mu / std tail: skinny layer launches when the shapes allow (the h5 slot of the workspace is free behind
+    // the fused max-pool's per-tile partials: it holds the slabs), else one un-split GEMM per layer
+    int sk = -2;
+    if (hp_skinny_enabled() && tail_slabs && B <= 64)
+        sk = enc_tail_forward_skinny(B, out_size, g, w, is_vae, f, mu, lv, tail_slabs, stream);
+    if (sk != -2) {
+        TRY(sk);
+    } else {
+        TRY(op.lin_fwd(g, 0, 512, w->fc_w, 0, w->fc_b, 0, f, 0, 512, B, 512, 512, 1, true));
+        TRY(op.lin_fwd(f, 0, 512, w->mu_w, 0, w->mu_b, 0, mu, 0, out_size, B, out_size, 512, 1, false));
+        if (is_vae) TRY(op.lin_fwd(f, 0, 512, w->std_w, 0, w->std_b, 0, lv, 0, out_size, B, out_size, 512, 1, false));
+    }
     if (is_vae) {
-        TRY(op.lin_fwd(f, 0, 512, w->std_w, 0, w->std_b, 0, lv, 0, out_size, B, out_size, 512, 1, false));
         const long n = (long)B * out_size;
         hipLaunchKernelGGL(vae_head_fwd_kernel, dim3((int)cdiv(n, 256)), dim3(256), 0, stream, n, eps, mu, lv, z, explv);
     }
@@ -616,15 +721,24 @@ HP_API int hp_encoder_backward(int B, int Np, const float* x, const HpEncoderWei
         hipLaunchKernelGGL(vae_head_bwd_kernel, dim3((int)cdiv(n, 256)), dim3(256), 0, stream, n, eps, lv, grad_out, grad_mu,
                            grad_explv, dmu, dlv);
         dmu_p = dmu;
-        TRY(op.lin_dw(dlv, 0, out_size, f, 0, 512, gr->std_w, 0, B, out_size, 512, 1, gr->std_b));
-        TRY(op.lin_dx(dlv, 0, out_size, w->std_w, 0, tmp, 0, 512, B, out_size, 512, 1, nullptr, 0, 0, nullptr, 0));
     } else {
         dmu_p = grad_out;
     }
-    TRY(op.lin_dw(dmu_p, 0, out_size, f, 0, 512, gr->mu_w, 0, B, out_size, 512, 1, gr->mu_b));
-    TRY(op.lin_dx(dmu_p, 0, out_size, w->mu_w, 0, dfc, 0, 512, B, out_size, 512, 1, f, 0, 512, is_vae ? tmp : nullptr, 512));
-    TRY(op.lin_dw(dfc, 0, 512, g, 0, 512, gr->fc_w, 0, B, 512, 512, 1, gr->fc_b));
-    TRY(op.lin_dx(dfc, 0, 512, w->fc_w, 0, dg, 0, 512, B, 512, 512, 1, nullptr, 0, 0, nullptr, 0));
+    int sk = -2;
+    if (hp_skinny_enabled() && B <= 64 && dmu_p)
+        sk = enc_tail_backward_skinny(B, out_size, g, f, w, dmu_p, is_vae ? dlv : nullptr, gr, dfc, dg, L.split, stream);
+    if (sk != -2) {
+        TRY(sk);
+    } else {
+        if (is_vae) {
+            TRY(op.lin_dw(dlv, 0, out_size, f, 0, 512, gr->std_w, 0, B, out_size, 512, 1, gr->std_b));
+            TRY(op.lin_dx(dlv, 0, out_size, w->std_w, 0, tmp, 0, 512, B, out_size, 512, 1, nullptr, 0, 0, nullptr, 0));
+        }
+        TRY(op.lin_dw(dmu_p, 0, out_size, f, 0, 512, gr->mu_w, 0, B, out_size, 512, 1, gr->mu_b));
+        TRY(op.lin_dx(dmu_p, 0, out_size, w->mu_w, 0, dfc, 0, 512, B, out_size, 512, 1, f, 0, 512, is_vae ? tmp : nullptr, 512));
+        TRY(op.lin_dw(dfc, 0, 512, g, 0, 512, gr->fc_w, 0, B, 512, 512, 1, gr->fc_b));
+        TRY(op.lin_dx(dfc, 0, 512, w->fc_w, 0, dg, 0, 512, B, 512, 512, 1, nullptr, 0, 0, nullptr, 0));
+    }
 
     // ---- conv stack on the critical rows (B*512 of them, or the distinct ones)
     const float* h4_full = fwd_ws ? fwd_ws + (long)B * Np * (64 + 128 + 256) : nullptr;
@@ -663,19 +777,7 @@ bool heads_contiguous(P const* hw, P const* hb, const int* out, int n) {
     return n > 0;
 }
 
-// ---- the trunk as skinny-M layer programs (skinny.hip): one persistent launch per direction --------------------
-int env_int(const char* name, int dflt) {
-    const char* e = std::getenv(name);
-    return e && *e ? std::atoi(e) : dflt;
-}
-// contraction ranges of a layer: a power of two, <= smax, each range at least 32 long, and no more tasks than CUs
-int sk_ranges(int contraction, int out_blocks, int smax) {
-    int s = 1;
-    while (2 * s <= smax && contraction / (2 * s) >= 32 && contraction % (2 * s) == 0 && out_blocks * 2 * s <= 256) s *= 2;
-    return s;
-}
-inline long up4(long v) { return (v + 3) / 4 * 4; }
-
+// ---- the trunk as skinny-M layer programs (skinny.hip): one latency-built launch per layer --------------------------
 // model/hyper_network.py:16-30, 41 (self.model(x)).  slabs: kSplitWs floats.  Returns -2 when the shapes do not fit.
 int trunk_forward_skinny(int B, int in_size, const float* latent, const HpHyperWeights* w, float* t, float* slabs,
                          hipStream_t stream) {

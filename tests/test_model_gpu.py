@@ -130,10 +130,22 @@ def test_gemm_device_side_sizes():
 
 
 # ----------------------------------------------------------------------------- components vs oracle
-def test_encoder_forward_backward_vs_oracle(ref):
+@pytest.mark.parametrize("skinny", [1, 0])
+def test_encoder_forward_backward_vs_oracle(ref, skinny):
+    """Forward and backward against the oracle, the fc/mu/std tail as skinny layer launches (csrc/skinny.hip; forward
+    only behind the fused max-pool, i.e. whole 128-point tiles per cloud) and as tiled GEMM launches."""
+    from hyperpocket_amd import _lib
+    prev = _lib.load_library().hp_skinny_set_enabled(skinny)
+    try:
+        _encoder_vs_oracle(ref)
+    finally:
+        _lib.load_library().hp_skinny_set_enabled(prev)
+
+
+def _encoder_vs_oracle(ref):
     from hyperpocket_amd.model.encoder import Encoder
     from hyperpocket_amd.core.setup import weights_init
-    for is_vae, B, Np in [(True, 3, 200), (False, 2, 1024), (True, 5, 37)]:
+    for is_vae, B, Np in [(True, 3, 200), (False, 2, 1024), (True, 5, 37), (True, 4, 1024), (True, 64, 128), (False, 33, 256)]:
         torch.manual_seed(3)
         enc = Encoder({"output_size": 128, "use_bias": True, "relu_slope": 0.2}, is_vae=is_vae)
         enc.apply(weights_init)
