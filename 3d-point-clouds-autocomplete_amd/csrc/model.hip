@@ -460,7 +460,7 @@ inline long up4(long v) { return (v + 3) / 4 * 4; }
 
 // model/encoder.py:46-53 after the max-pool: f = ReLU(fc g) ; mu = mu_layer f ; lv = std_layer f.  Two launches (the fc
 // layer in k-ranges whose slabs the mu/std tasks finish on load, writing f on the way) instead of 3 un-split GEMMs of
-// ~19 us each.  slabs: 4*64*512 floats.  Returns -2 when the shapes do not fit.
+// ~19 us each.  slabs: 4*64*512 + 8*64*out_size floats.  Returns -2 when the shapes do not fit.
 int enc_tail_forward_skinny(int B, int out_size, const float* g, const HpEncoderWeights* w, int is_vae, float* f, float* mu,
                             float* lv, float* slabs, hipStream_t stream) {
     if (B > 64 || out_size % 32) return -2;
@@ -476,14 +476,31 @@ int enc_tail_forward_skinny(int B, int out_size, const float* g, const HpEncoder
     HpSkSrc fsrc{};
     fsrc.p = slabs; fsrc.slab = 64L * 512; fsrc.S = S; fsrc.ld = 512; fsrc.bias = w->fc_b; fsrc.relu = 1;
     fsrc.mat = f; fsrc.ldmat = 512;
+    // mu / std heads: 4 strips each — k-ranges again (16 tasks of one memory latency instead of 4 tasks of eight), their
+    // slabs finished by a last launch
+    const int Sh = sk_ranges(512, out_size / 32, 4);
+    float* hs = slabs + (long)S * 64 * 512;
     for (int hd = 0; hd < (is_vae ? 2 : 1); ++hd) {
         HpSkOp& op = pr.op[pr.nops++];
         op.type = HP_SK_F; op.phase = 1;
         op.a = fsrc;
         if (hd) op.a.mat = nullptr;          // f is written once, by the mu tasks
         op.w = hd ? w->std_w : w->mu_w; op.w_ld = 512;
-        op.M = B; op.N = out_size; op.K = 512; op.CL = 512;
-        op.out = hd ? lv : mu; op.out_ld = out_size; op.out_bias = hd ? w->std_b : w->mu_b;
+        op.M = B; op.N = out_size; op.K = 512; op.CL = 512 / Sh;
+        op.out_ld = out_size;
+        if (Sh == 1) {
+            op.out = hd ? lv : mu; op.out_bias = hd ? w->std_b : w->mu_b;
+        } else {
+            op.out = hs + (long)hd * Sh * 64 * out_size; op.out_slab = 64L * out_size;
+        }
+    }
+    for (int hd = 0; hd < (is_vae ? 2 : 1) && Sh > 1; ++hd) {
+        HpSkOp& op = pr.op[pr.nops++];
+        op.type = HP_SK_FIN; op.phase = 2;
+        op.a.p = hs + (long)hd * Sh * 64 * out_size; op.a.slab = 64L * out_size; op.a.S = Sh; op.a.ld = out_size;
+        op.a.bias = hd ? w->std_b : w->mu_b;
+        op.out = hd ? lv : mu; op.out_ld = out_size;
+        op.M = B; op.N = out_size; op.K = 1;
     }
     return hp_skinny_run(&pr, stream);
 }
@@ -582,7 +599,7 @@ HP_API int hp_encoder_forward(int B, int Np, const float* x, const HpEncoderWeig
         const long tiles = R / tr;
         d5.cmax = h[5];
         d5.cidx = reinterpret_cast<int*>(h[5] + tiles * 512);
-        if (R * 512 - up4(2 * tiles * 512) >= 4L * 64 * 512) tail_slabs = h[5] + up4(2 * tiles * 512);
+        if (R * 512 - up4(2 * tiles * 512) >= 4L * 64 * 512 + 8L * 64 * out_size) tail_slabs = h[5] + up4(2 * tiles * 512);
         TRY(hp_gemm_f32(&d5, stream));
         hipLaunchKernelGGL(colmax_tiles_kernel, dim3(2, B), dim3(256), 0, stream, d5.cmax, d5.cidx, Np / tr, tr, 512, g, argidx);
     } else {

@@ -83,9 +83,13 @@ __device__ __forceinline__ float4 src_load4(const HpSkSrc& a, int row, int c) {
 }
 
 // One staged chunk of a source in flight: columns [c0, c0+CL) of all 64 rows, CL = 16*NG, lanes along the columns, NG
-// groups of 4 columns per thread x S <= 4 slabs.  load() only ISSUES; store() finishes (range-ordered slab sum, bias,
-// ReLU, mask) into As[64][CL+4] (rows >= M are zero) and, for the designated reader, into the source's `mat`.
-template <int NG, int SB>   // SB: slabs held per group (1: an already finished source, 4: up to four partial slabs)
+// groups of 4 columns per thread x SB slab slots.  load() only ISSUES, and it is BRANCH-FREE (rows >= M re-read row M-1,
+// slab slots >= S re-read slab 0, the auxiliary operand always comes from a valid address): inside one basic block the
+// compiler counts the loads in flight exactly, so staging chunk c waits for chunk c's loads only while chunk c+1's stay
+// in flight; a predicated load costs that (measured: every chunk then paid a full memory latency).
+// store() finishes (range-ordered slab sum, bias, ReLU, mask) into As[64][CL+4] (rows >= M are zero) and, for the
+// designated reader, into the source's `mat`.
+template <int NG, int SB>   // SB: slab slots held per group (1: an already finished source, 4: up to four partial slabs)
 struct SrcChunk {
     static constexpr int CL = NG * 16, ldl = CL + 4, QR = CL / 4;
     float4 t[NG][SB], aux[NG];
@@ -93,52 +97,52 @@ struct SrcChunk {
     __device__ __forceinline__ void load(const HpSkSrc& a, int M, int c0_) {
         c0 = c0_;
         const Buf buf(a.p);
+        // the auxiliary operand: bias(col) | mask(row, col) | (neither: the source itself, value unused)
+        const float* auxp = a.bias ? a.bias : (a.mask ? a.mask : a.p);
+        const int aux_ld = a.bias ? 0 : (a.mask ? a.ldm : a.ld);
 #pragma unroll
         for (int e = 0; e < NG; ++e) {
-            const int idx = threadIdx.x + e * kThreads, row = idx / QR, q = idx % QR;
+            const int idx = threadIdx.x + e * kThreads, row = min(idx / QR, M - 1), q = idx % QR;
             const long off = (long)row * a.ld + c0 + 4 * q;
 #pragma unroll
-            for (int u = 0; u < SB; ++u)
-                if (row < M && u < a.S) t[e][u] = buf.ld4(off + (long)u * a.slab);
-            if (a.bias) aux[e] = *reinterpret_cast<const float4*>(a.bias + c0 + 4 * q);
-            if (a.mask && row < M) aux[e] = *reinterpret_cast<const float4*>(a.mask + (long)row * a.ldm + c0 + 4 * q);
+            for (int u = 0; u < SB; ++u) t[e][u] = buf.ld4(off + (long)(u < a.S ? u : 0) * a.slab);
+            aux[e] = *reinterpret_cast<const float4*>(auxp + (long)row * aux_ld + c0 + 4 * q);
         }
     }
     __device__ __forceinline__ void store(const HpSkSrc& a, int M, float* As, bool materialise) const {
 #pragma unroll
         for (int e = 0; e < NG; ++e) {
             const int idx = threadIdx.x + e * kThreads, row = idx / QR, q = idx % QR;
-            float4 f = f4zero();
-            if (row < M) {
-                float4 v = t[e][0];
+            float4 v = t[e][0];
 #pragma unroll
-                for (int u = 1; u < SB; ++u)
-                    if (u < a.S) v = f4add(v, t[e][u]);
-                f = src_finish(a, v, aux[e]);
-            }
+            for (int u = 1; u < SB; ++u)
+                if (u < a.S) v = f4add(v, t[e][u]);
+            float4 f = src_finish(a, v, aux[e]);
+            if (row >= M) f = f4zero();
             *reinterpret_cast<float4*>(&As[row * ldl + 4 * q]) = f;
             if (materialise && row < M) *reinterpret_cast<float4*>(a.mat + (long)row * a.ldmat + c0 + 4 * q) = f;
         }
     }
 };
 
-// Columns [c0, c0+CL) of weight rows [n0, n0+32) (clamped to N-1): NG/2 groups per thread.
+// Columns [c0, c0+CL) of weight rows [n0, n0+32) (clamped to N-1): NG/2 groups per thread, branch-free.
 template <int NG>
 struct WChunk {
-    static constexpr int CL = NG * 16, ldl = CL + 4, QR = CL / 4, total = 32 * QR, NV = (NG + 1) / 2;
+    static constexpr int CL = NG * 16, ldl = CL + 4, QR = CL / 4, NV = NG / 2;
+    static_assert(NV * kThreads == 32 * QR, "whole passes of the workgroup over the block");
     float4 v[NV];
     __device__ __forceinline__ void load(const float* __restrict__ W, int ld, int N, int n0, int c0) {
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
             const int idx = threadIdx.x + e * kThreads;
-            if (idx < total) v[e] = *reinterpret_cast<const float4*>(W + (long)min(n0 + idx / QR, N - 1) * ld + c0 + 4 * (idx % QR));
+            v[e] = *reinterpret_cast<const float4*>(W + (long)min(n0 + idx / QR, N - 1) * ld + c0 + 4 * (idx % QR));
         }
     }
     __device__ __forceinline__ void store(float* Ws) const {
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
             const int idx = threadIdx.x + e * kThreads;
-            if (idx < total) *reinterpret_cast<float4*>(&Ws[(idx / QR) * ldl + 4 * (idx % QR)]) = v[e];
+            *reinterpret_cast<float4*>(&Ws[(idx / QR) * ldl + 4 * (idx % QR)]) = v[e];
         }
     }
 };
@@ -294,11 +298,13 @@ __device__ __forceinline__ void task_w(const HpSkOp& op, int t) {
     float av[32], bv[32];
 #pragma unroll
     for (int s = 0; s < 32; ++s) {
-        const int m = 2 * s + h;
-        const bool ok = m < op.M;
-        av[s] = ok ? ap[(long)m * op.a.ld] : 0.f;
-        bv[s] = ok ? bp[(long)m * op.w_ld] : 0.f;
+        const int m = min(2 * s + h, op.M - 1);      // branch-free: all 64 loads in flight; rows >= M zeroed below
+        av[s] = ap[(long)m * op.a.ld];
+        bv[s] = bp[(long)m * op.w_ld];
     }
+#pragma unroll
+    for (int s = 0; s < 32; ++s)
+        if (2 * s + h >= op.M) av[s] = 0.f;
     f32x16 acc = {};
     float asum = 0.f;
 #pragma unroll
@@ -332,8 +338,12 @@ __device__ __forceinline__ void task_fin(const HpSkOp& op, int t) {
 // One phase: ops [op_begin, op_end) of the program, their tasks dealt round-robin over the grid.  Chunk depth: 128 for a
 // finished source (one 16-byte load per group), 64 for a source in up to four slabs — either way two chunks = 32 16-byte
 // loads per thread are in flight (deeper spills past the 512 registers).
+// LIGHT: a phase of W / FIN tasks only — the same loop compiled without the F / X bodies needs a quarter of the registers,
+// so its workgroups find room beside another stream's GEMM workgroups instead of waiting for a whole CU to drain (a FIN
+// phase of the first encoder's tail sat 270 us behind the other encoder's conv5 that way).
+template <bool LIGHT>
 __global__ __launch_bounds__(kThreads) void skinny_kernel(const Prog g_arg) {
-    __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
+    __shared__ __attribute__((aligned(16))) float lds[LIGHT ? 4 : kLdsFloats];
     const int G = gridDim.x;
     // The program is indexed with a run-time op number: read it where it lies, in the kernel-argument segment (scalar
     // loads), instead of letting the compiler copy the by-value struct to scratch memory to index it.
@@ -347,7 +357,7 @@ __global__ __launch_bounds__(kThreads) void skinny_kernel(const Prog g_arg) {
         if (first < 0) first += G;
         const int cl = min(op.CL, kCLMax);
         for (int t = first; t < op.ntasks; t += G) {
-            if (op.type == HP_SK_F) {
+            if (!LIGHT && op.type == HP_SK_F) {
                 if (op.a.S == 1) {
                     if (cl == 128) task_f<8, 1>(op, t, lds);
                     else if (cl == 64) task_f<4, 1>(op, t, lds);
@@ -356,7 +366,7 @@ __global__ __launch_bounds__(kThreads) void skinny_kernel(const Prog g_arg) {
                     if (cl >= 64) task_f<4, 4>(op, t, lds);
                     else task_f<2, 4>(op, t, lds);
                 }
-            } else if (op.type == HP_SK_X) {
+            } else if (!LIGHT && op.type == HP_SK_X) {
                 if (op.a.S == 1) {
                     if (cl == 128) task_x<8, 1>(op, t, lds);
                     else if (cl == 64) task_x<4, 1>(op, t, lds);
@@ -367,7 +377,7 @@ __global__ __launch_bounds__(kThreads) void skinny_kernel(const Prog g_arg) {
                 }
             } else if (op.type == HP_SK_W) {
                 task_w(op, t);
-            } else {
+            } else if (op.type == HP_SK_FIN) {
                 task_fin(op, t);
             }
         }
@@ -446,10 +456,16 @@ int hp_skinny_run(HpSkProgram* prog, hipStream_t stream) {
     // one launch per phase: the kernel boundary orders the phases
     for (int b = 0; b < prog->nops;) {
         int e = b, tasks = 0;
-        while (e < prog->nops && prog->op[e].phase == prog->op[b].phase) tasks += prog->op[e++].ntasks;
+        bool light = true;
+        for (; e < prog->nops && prog->op[e].phase == prog->op[b].phase; ++e) {
+            tasks += prog->op[e].ntasks;
+            light = light && (prog->op[e].type == HP_SK_W || prog->op[e].type == HP_SK_FIN);
+        }
         g.op_begin = b;
         g.op_end = e;
-        hipLaunchKernelGGL(skinny_kernel, dim3(std::max(1, std::min(tasks, 512))), dim3(kThreads), 0, stream, g);
+        const dim3 grid(std::max(1, std::min(tasks, 512)));
+        if (light) hipLaunchKernelGGL(skinny_kernel<true>, grid, dim3(kThreads), 0, stream, g);
+        else hipLaunchKernelGGL(skinny_kernel<false>, grid, dim3(kThreads), 0, stream, g);
         b = e;
     }
     HP_RETURN_LAST_ERROR();

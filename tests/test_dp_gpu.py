@@ -101,9 +101,13 @@ def test_two_rank_engine_matches_single_process_global_batch(shard):
         eng.finish_pending()
         for k, p in model.named_parameters():
             a, b = got[k].double(), p.detach().cpu().double()
-            # Adam's update is ~lr*sign(g): tiny-gradient elements may flip under a different summation order
-            assert (a - b).abs().max().item() <= 2.5e-4, k
-            assert (a - b).abs().mean().item() <= 2e-6, k
+            # Adam's first updates are ~lr*sign(g) (lr = 1e-4): an element whose gradient is rounding noise may take the
+            # other sign under a different summation order (two ranks of 4 clouds vs one process of 8) — at most
+            # 2*lr per step, 4e-4 after the two steps — and only a handful of elements may do so
+            d = (a - b).abs()
+            assert d.max().item() <= 4.1e-4, k
+            assert (d > 1e-5).double().mean().item() <= 2e-3, k
+            assert d.mean().item() <= 2e-6, k
         # the optimiser checkpoint written under DP (heads' Adam moments row-sharded over the ranks, gathered by
         # optimizer_state_dict) equals the single-process optimiser state on the global batch
         want_opt = eng.optimizer_state_dict()["state"]

@@ -2,7 +2,7 @@
 """Timeline of the last engine step in a rocprofv3 kernel trace of bench.py: per-queue lanes, gaps, overlap."""
 import csv, glob, sys
 d = sys.argv[1]
-f = glob.glob(d + '/*/*_kernel_trace.csv')[0]
+f = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 # step boundaries: adam_kernel launches (several buckets per step); find the last 'sample_points' -> next 'sample_points'
 idx = [i for i, r in enumerate(rows) if 'sample_points' in r['Kernel_Name']]
