@@ -609,7 +609,12 @@ __global__ __launch_bounds__(256) void emd_cost_finish_kernel(const float* __res
     if (threadIdx.x == 0) out[blockIdx.x] = (float)t;
 }
 
-int run_levels(int b, int n, int m, const float* xyz1, const float* xyz2, float* temp, float* ws, Ctx* out, hipStream_t stream) {
+// final_remainL: also run phase 3 of the last level.  Its only products are the last `match +=` term — which the match pass
+// and the cost/gradient sweeps re-evaluate from the final records — and remainL's final value in `temp`: the API path
+// (hp_approxmatch_ws) returns that, the match-free training path (hp_emd_forward) has no reader for it and skips the
+// launch (one of 28 exponential sweeps, 55 us at B=64, N=2048).
+int run_levels(int b, int n, int m, const float* xyz1, const float* xyz2, float* temp, float* ws, Ctx* out, hipStream_t stream,
+               bool final_remainL) {
     const WsLayout L = ws_layout(n, m);
     Ctx c{n, m, L.NP, L.MP, xyz1, xyz2, temp, ws, L.plp, L.prp, L.rr, L.flp, L.frp, L.per_cloud};
     float multiL, multiR;
@@ -651,7 +656,7 @@ int run_levels(int b, int n, int m, const float* xyz1, const float* xyz2, float*
             hipLaunchKernelGGL(emd_rows2_kernel<1>, g2, dim3(kThreads), 0, stream, c, lev, level_l2e(lev));
         if (lev + 1 < kLevels)
             HP_ROWS1(true, true, c, lev + 1, level_l2e(lev), level_l2e(lev + 1));
-        else
+        else if (final_remainL)
             HP_ROWS1(true, false, c, lev, level_l2e(lev), 0.f);
     }
 #undef HP_ROWS1
@@ -796,7 +801,7 @@ HP_API int hp_approxmatch_ws(int b, int n, int m, const float* xyz1, const float
     if (b == 0) return 0;
     HP_CHECK_ARG(xyz1 && xyz2 && match && temp && ws && b <= 65535);
     Ctx c;
-    int rc = run_levels(b, n, m, xyz1, xyz2, temp, ws, &c, stream);
+    int rc = run_levels(b, n, m, xyz1, xyz2, temp, ws, &c, stream, true);
     if (rc) return rc;
     hipLaunchKernelGGL(emd_match_kernel, dim3((n + kThreads - 1) / kThreads, (m + kLT - 1) / kLT, b), dim3(kThreads), 0, stream, c,
                        match);
@@ -816,7 +821,7 @@ HP_API int hp_emd_forward(int b, int n, int m, const float* xyz1, const float* x
     if (b == 0) return 0;
     HP_CHECK_ARG(xyz1 && xyz2 && temp && ws && partials && cost && b <= 65535);
     Ctx c;
-    int rc = run_levels(b, n, m, xyz1, xyz2, temp, ws, &c, stream);
+    int rc = run_levels(b, n, m, xyz1, xyz2, temp, ws, &c, stream, false);   // temp is scratch here
     if (rc) return rc;
     const int nb = (n + kRowsPerWg - 1) / kRowsPerWg, mb = (m + kRowsPerWg - 1) / kRowsPerWg;
     if (grad2) {

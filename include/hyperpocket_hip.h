@@ -59,7 +59,8 @@ int hp_emd_set_rows_per_lane(int rows1, int rows2, int grad2);
  * writing the (b,m,n) match tensor): cost (b,) plus whichever of grad1 = d cost/d xyz1, grad2 = d cost/d xyz2 the
  * caller asks for (the cost rides on one of those sweeps); hp_emd_backward computes grad2 later from the packed
  * records hp_emd_forward left in `ws` (hp_approxmatch_workspace_floats).
- * partials: hp_emd_partials_floats floats.  temp as in hp_approxmatch; ws as in hp_approxmatch_ws. */
+ * partials: hp_emd_partials_floats floats.  temp: scratch of hp_approxmatch's size (its remainL block is left one level
+ * short: the last level's phase 3 has no reader on this path and is not launched); ws as in hp_approxmatch_ws. */
 long hp_emd_partials_floats(int b, int n, int m);
 int hp_emd_forward(int b, int n, int m, const float* xyz1, const float* xyz2, float* temp, float* ws, float* partials,
                    float* cost, float* grad1 /* or NULL */, float* grad2 /* or NULL */, hpStream_t stream);
