@@ -224,9 +224,9 @@ def roofline_emd(batch, n):
     g2 = torch.empty((batch, n, 3), **f32)
     st = current_stream(a.device)
     ms = event_time_ms(lambda: call("hp_emd_forward", batch, n, n, a, c, temp, ws, part, cost, None, g2, st), iters=20, warm=10)
-    out = {"bound": "valu-issue", "kernel": "hp_emd_forward = emd_rows1_kernel x10 + emd_rows2_kernel x9 + emd_grad2_kernel "
+    out = {"bound": "valu-issue", "kernel": "hp_emd_forward = emd_rows1_kernel x9 + emd_rows2_kernel x9 + emd_grad2_kernel "
            f"(B={batch}, n=m={n}, grad2 + cost)", "avg_call_ms": round(ms, 4), "peak": round(PEAK_VALU_ISSUE_TCYC, 4),
-           "unit": "T issue-cycles/s", "exp_per_call": 37.0 * batch * n * n}
+           "unit": "T issue-cycles/s", "exp_per_call": 36.0 * batch * n * n}
     if model and model.get("batch") == batch and model.get("n") == n:
         cyc = model["issue_cycles_per_call"]
         out.update({"achieved": round(cyc / (ms * 1e-3) / 1e12, 4), "frac": round(cyc / (ms * 1e-3) / 1e12 / PEAK_VALU_ISSUE_TCYC, 4),

@@ -96,7 +96,7 @@ def main():
     plan = [  # (kernel instance, launches per call, rows per lane, candidates per loop iteration)
         (f"emd_rows1_kernel<false, true, {r1}>", 1, r1, 16),
         (f"emd_rows1_kernel<true, true, {r1}>", 8, r1, 16),
-        (f"emd_rows1_kernel<true, false, {r1}>", 1, r1, 16),
+        # (the last level's phase 3, emd_rows1_kernel<true, false, .>, is not launched on this path: no reader)
         (f"emd_rows2_kernel<{r2}>", 9, r2, 16),
         (f"emd_grad2_kernel<true, {g2}>", 1, g2, 4),
     ]
