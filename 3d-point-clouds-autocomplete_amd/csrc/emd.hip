@@ -31,7 +31,10 @@
 
 namespace {
 
-constexpr int kThreads = 256;
+#ifndef HP_EMD_PARTS
+#define HP_EMD_PARTS 4
+#endif
+constexpr int kThreads = 64 * HP_EMD_PARTS;   // one wave per candidate range, 64 rows per workgroup
 constexpr int kLevels = 9;
 constexpr int kStage = 8;   // candidates per software-pipeline stage of the phase kernels (= 4 pair records)
 constexpr int kSpare = 8;   // readable zero candidates past the padded range (the prefetch after the last stage)
@@ -57,7 +60,7 @@ __host__ __device__ constexpr float level_l2e(int lev) {
 // into kParts contiguous ranges handled by different waves of the workgroup and added in range order through LDS
 // (ordered, deterministic; a reordering of the reference's sequential sum that moves the cost by ~1e-7 relative —
 // measured on the oracle — against 1e-5 for the exp formulation).
-constexpr int kParts = 4;
+constexpr int kParts = HP_EMD_PARTS;
 constexpr int kRowsPerWg = kThreads / kParts;
 inline int pad_up(int x) { return (x + 2 * kStage * kParts - 1) / (2 * kStage * kParts) * (2 * kStage * kParts); }
 
