@@ -33,9 +33,10 @@ constexpr int kThreads = 256;
 constexpr int kCLMax = 128;                       // contraction chunk staged per pass
 constexpr int kLdsFloats = 96 * (kCLMax + 4);     // staged A (64 rows) + W (32 rows) blocks; the cross-wave reduce aliases them
 
-struct Prog {
-    HpSkProgram p;
-    int op_begin, op_end;
+constexpr int kPhaseOps = 4;   // ops per launch (a phase with more is split: its ops are independent)
+struct Prog {                  // the kernel argument: only the launch's own ops (the CPU copies it per launch)
+    int nops;
+    HpSkOp op[kPhaseOps];
 };
 
 
@@ -335,7 +336,7 @@ __device__ __forceinline__ void task_fin(const HpSkOp& op, int t) {
     *reinterpret_cast<float4*>(op.out + (long)r * op.out_ld + 4 * q) = src_load4(op.a, r, 4 * q);
 }
 
-// One phase: ops [op_begin, op_end) of the program, their tasks dealt round-robin over the grid.  Chunk depth: 128 for a
+// One phase (<= kPhaseOps ops of the program), the ops' tasks dealt round-robin over the grid.  Chunk depth: 128 for a
 // finished source (one 16-byte load per group), 64 for a source in up to four slabs — either way two chunks = 32 16-byte
 // loads per thread are in flight (deeper spills past the 512 registers).
 // LIGHT: a phase of W / FIN tasks only — the same loop compiled without the F / X bodies needs a quarter of the registers,
@@ -350,8 +351,8 @@ __global__ __launch_bounds__(kThreads) void skinny_kernel(const Prog g_arg) {
     const Prog& g = *(const Prog*)__builtin_amdgcn_kernarg_segment_ptr();
     (void)g_arg;
     int base = 0;
-    for (int o = g.op_begin; o < g.op_end; ++o) {
-        const HpSkOp& op = g.p.op[o];
+    for (int o = 0; o < g.nops; ++o) {
+        const HpSkOp& op = g.op[o];
         // ops of one phase start on different workgroups
         int first = (int)blockIdx.x - base % G;
         if (first < 0) first += G;
@@ -449,20 +450,19 @@ int hp_skinny_run(HpSkProgram* prog, hipStream_t stream) {
         }
         maxtasks = std::max(maxtasks, op.ntasks);
     }
-    Prog g;
-    g.p = *prog;
     (void)phases;
     (void)maxtasks;
     // one launch per phase: the kernel boundary orders the phases
     for (int b = 0; b < prog->nops;) {
+        Prog g;
+        g.nops = 0;
         int e = b, tasks = 0;
         bool light = true;
-        for (; e < prog->nops && prog->op[e].phase == prog->op[b].phase; ++e) {
+        for (; e < prog->nops && prog->op[e].phase == prog->op[b].phase && g.nops < kPhaseOps; ++e) {
+            g.op[g.nops++] = prog->op[e];
             tasks += prog->op[e].ntasks;
             light = light && (prog->op[e].type == HP_SK_W || prog->op[e].type == HP_SK_FIN);
         }
-        g.op_begin = b;
-        g.op_end = e;
         const dim3 grid(std::max(1, std::min(tasks, 512)));
         if (light) hipLaunchKernelGGL(skinny_kernel<true>, grid, dim3(kThreads), 0, stream, g);
         else hipLaunchKernelGGL(skinny_kernel<false>, grid, dim3(kThreads), 0, stream, g);
