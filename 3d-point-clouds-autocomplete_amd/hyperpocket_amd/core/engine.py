@@ -191,7 +191,8 @@ class TrainEngine:
         """One optimisation step on this rank's shard.  Tensors are (B,N,3) device tensors; returns the
         loss terms as 0-dim device tensors (no host sync)."""
         model = self.model
-        model.train()
+        if not model.training:
+            model.train()          # (recursive over ~50 modules: 0.2 ms of host time when called every step)
         assert self.flat.is_intact(), "parameters were re-allocated (e.g. .to()) after TrainEngine construction"
         self.flat.clear_param_grads()
         device = gt.device
