@@ -632,6 +632,36 @@ def test_train_engine_with_emd_term_runs_and_decreases_loss():
         ops.clear_grad_views()
 
 
+def test_train_engine_steps_are_bit_identical_run_to_run():
+    """No kernel of the step uses atomics or an unordered reduction (slab sums in range order, ordered workgroup partials,
+    fixed-point LDS accumulation in the Chamfer gradient): two engines built from the same seed and fed the same batch,
+    decoder points and noise end three Chamfer+EMD steps with IDENTICAL parameters — through the skinny layer launches and
+    through the tiled GEMM launches."""
+    from hyperpocket_amd import _lib, ops
+    from hyperpocket_amd.core.engine import TrainEngine
+    g = torch.Generator().manual_seed(11)
+    ex, mi = (torch.rand(6, 256, 3, generator=g) - 0.5).cuda(), (torch.rand(6, 256, 3, generator=g) - 0.5).cuda()
+    gt = torch.cat([ex, mi], 1)
+    pts, eps = (torch.rand(6, 512, 3, generator=g) * 2 - 1).cuda(), torch.randn(6, 128, generator=g).cuda()
+    for skinny in (1, 0):
+        prev = _lib.load_library().hp_skinny_set_enabled(skinny)
+        try:
+            runs = []
+            for _ in range(2):
+                model = build_model(2020)
+                eng = TrainEngine(model, emd_coef=0.05)
+                for _ in range(3):
+                    eng.step(ex, mi, gt, 7, points=pts, eps_noise=eps)
+                eng.synchronize()
+                runs.append({k: p.detach().clone() for k, p in model.named_parameters()})
+                ops.clear_grad_views()
+            for k in runs[0]:
+                assert torch.equal(runs[0][k], runs[1][k]), (skinny, k)
+        finally:
+            _lib.load_library().hp_skinny_set_enabled(prev)
+            ops.clear_grad_views()
+
+
 def test_train_engine_chamfer_plus_emd_step_vs_oracle(ref):
     """The bench workload's step (0.05*Chamfer + KLD/B + 0.05*EMD/N, Adam) against the oracle's same step on CPU."""
     from hyperpocket_amd.core.engine import TrainEngine
