@@ -1,10 +1,11 @@
 // Skinny-M layer programs on gfx950 — the M = B <= 64 chains of the HyperPocket step:
 //   hypernetwork trunk, forward and backward   /root/reference/model/hyper_network.py:16-30 (+ the autograd of it)
+//   encoder fc / mu / std tail                  /root/reference/model/encoder.py:30-36,46-53 (+ the autograd of it)
 // With 64 rows these layers hold almost no arithmetic (0.35 GFLOP for the whole trunk against 11 MB of weights): as
 // tiled GEMMs they were ~26 dependent launches of 5-10 us each, every one a latency chain (a k-loop of round trips to
 // memory, then a split-K reduce launch).  Here a layer is ONE launch ("phase") and every launch is built around memory
 // latency instead of tiles: all workgroups take (output strip x contraction range) tasks, issue every global load of a
-// task up front (two 128-deep chunks in flight: a task pays about one memory latency), contract on the matrix cores
+// task up front (two 64/128-deep chunks in flight: a task pays about one memory latency), contract on the matrix cores
 // (v_mfma_f32_32x32x2_f32, exact fp32) and leave raw partial slabs; the next phase FINISHES its input while loading it
 // (slab sum in range order + bias + ReLU, or the ReLU mask of the backward) — no reduce launches, no atomics,
 // run-to-run identical.  Three task shapes:
@@ -18,7 +19,7 @@
 // L2s are not coherent with each other, so a barrier needs either agent-scope release/acquire (buffer_wbl2 + buffer_inv:
 // ~11 us per barrier with nothing dirty) or sc1 (memory-side) accesses for everything the phases exchange — then an
 // atomic-free flag barrier costs ~4 us, but the slab re-reads that the per-XCD L2 absorbs for free in separate launches
-// all go to the memory side: 88 us per direction against 68 us as six launches.
+// all go to the memory side: 88 us per direction against 68 us as six launches (DESIGN.md 7b).
 #include "hp_common.h"
 #include "hp_skinny.h"
 #include <algorithm>
@@ -38,7 +39,6 @@ struct Prog {                  // the kernel argument: only the launch's own ops
     int nops;
     HpSkOp op[kPhaseOps];
 };
-
 
 struct Buf {               // raw buffer over [base, base + 2 GB): 32-bit offsets
     __amdgpu_buffer_rsrc_t r;
