@@ -196,36 +196,48 @@ __device__ __forceinline__ void task_f(const HpSkOp& op, int t, float* lds) {
     SrcChunk<NG, SB> sc[2];
     WChunk<NG> wc[2];
     const int c_first = range * op.CL;
+    auto mfma_chunk = [&]() {
+#pragma unroll
+        for (int kq = 0; kq < ks / 8; ++kq) {
+            const int kk = w * ks + kq * 8;
+            const float4 a0 = *reinterpret_cast<const float4*>(&As[i * ldl + kk + 4 * h]);
+            const float4 a1 = *reinterpret_cast<const float4*>(&As[(32 + i) * ldl + kk + 4 * h]);
+            const float4 bb = *reinterpret_cast<const float4*>(&Ws[i * ldl + kk + 4 * h]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(a0, s), f4get(bb, s), acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(a1, s), f4get(bb, s), acc[1], 0, 0, 0);
+            }
+        }
+    };
+    // The next chunk's loads are issued UNCONDITIONALLY (past the end they re-read the last chunk, unused): with a
+    // conditional prefetch the compiler cannot know how many loads are in flight when it stages the current chunk and
+    // falls back to s_waitcnt vmcnt(0) — which also waits for the prefetch, i.e. no overlap at all.
     wc[0].load(op.w, op.w_ld, op.N, strip * 32, c_first);
     sc[0].load(op.a, op.M, c_first);
 #pragma unroll 1
     for (int ch = 0; ch < chunks; ch += 2) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            if (ch + b < chunks) {
-                if (ch + b + 1 < chunks) {       // next chunk's loads go out before this one is consumed
-                    const int c1 = c_first + (ch + b + 1) * CL;
-                    wc[b ^ 1].load(op.w, op.w_ld, op.N, strip * 32, c1);
-                    sc[b ^ 1].load(op.a, op.M, c1);
-                }
-                if (ch + b) __syncthreads();     // the previous chunk's fragments are read
-                sc[b].store(op.a, op.M, As, mat);
-                wc[b].store(Ws);
-                __syncthreads();
-#pragma unroll
-                for (int kq = 0; kq < ks / 8; ++kq) {
-                    const int kk = w * ks + kq * 8;
-                    const float4 a0 = *reinterpret_cast<const float4*>(&As[i * ldl + kk + 4 * h]);
-                    const float4 a1 = *reinterpret_cast<const float4*>(&As[(32 + i) * ldl + kk + 4 * h]);
-                    const float4 bb = *reinterpret_cast<const float4*>(&Ws[i * ldl + kk + 4 * h]);
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(a0, s), f4get(bb, s), acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(a1, s), f4get(bb, s), acc[1], 0, 0, 0);
-                    }
-                }
-            }
+        {
+            const int c1 = c_first + min(ch + 1, chunks - 1) * CL;
+            wc[1].load(op.w, op.w_ld, op.N, strip * 32, c1);
+            sc[1].load(op.a, op.M, c1);
         }
+        if (ch) __syncthreads();                 // the previous chunk's fragments are read
+        sc[0].store(op.a, op.M, As, mat);
+        wc[0].store(Ws);
+        __syncthreads();
+        mfma_chunk();
+        if (ch + 1 >= chunks) break;             // a single-chunk range
+        {
+            const int c2 = c_first + min(ch + 2, chunks - 1) * CL;
+            wc[0].load(op.w, op.w_ld, op.N, strip * 32, c2);
+            sc[0].load(op.a, op.M, c2);
+        }
+        __syncthreads();
+        sc[1].store(op.a, op.M, As, mat);
+        wc[1].store(Ws);
+        __syncthreads();
+        mfma_chunk();
     }
     reduce_store(acc, lds, op, op.out + (long)range * op.out_slab, op.N, strip * 32, nr == 1);
 }
@@ -253,35 +265,43 @@ __device__ __forceinline__ void task_x(const HpSkOp& op, int t, float* lds) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) dst[4 * g + s] = wp[(long)(8 * g + s) * op.w_ld];
     };
+    auto mfma_chunk = [&](const float (&bwc)[ns / 2]) {
+#pragma unroll
+        for (int g = 0; g < ns / 8; ++g) {
+            const int kk = w * ns + 8 * g;
+            const float4 a0 = *reinterpret_cast<const float4*>(&As[i * ldl + kk + 4 * h]);
+            const float4 a1 = *reinterpret_cast<const float4*>(&As[(32 + i) * ldl + kk + 4 * h]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(a0, s), bwc[4 * g + s], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(a1, s), bwc[4 * g + s], acc[1], 0, 0, 0);
+            }
+        }
+    };
     const int n_first = range * op.CL;
     load_b(n_first, bw[0]);
     sc[0].load(op.a, op.M, n_first);
 #pragma unroll 1
-    for (int ch = 0; ch < chunks; ch += 2) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            if (ch + b < chunks) {
-                if (ch + b + 1 < chunks) {
-                    const int n1 = n_first + (ch + b + 1) * CL;
-                    load_b(n1, bw[b ^ 1]);
-                    sc[b ^ 1].load(op.a, op.M, n1);
-                }
-                if (ch + b) __syncthreads();
-                sc[b].store(op.a, op.M, As, mat);
-                __syncthreads();
-#pragma unroll
-                for (int g = 0; g < ns / 8; ++g) {
-                    const int kk = w * ns + 8 * g;
-                    const float4 a0 = *reinterpret_cast<const float4*>(&As[i * ldl + kk + 4 * h]);
-                    const float4 a1 = *reinterpret_cast<const float4*>(&As[(32 + i) * ldl + kk + 4 * h]);
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(a0, s), bw[b][4 * g + s], acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(a1, s), bw[b][4 * g + s], acc[1], 0, 0, 0);
-                    }
-                }
-            }
+    for (int ch = 0; ch < chunks; ch += 2) {     // unconditional prefetch: see task_f
+        {
+            const int n1 = n_first + min(ch + 1, chunks - 1) * CL;
+            load_b(n1, bw[1]);
+            sc[1].load(op.a, op.M, n1);
         }
+        if (ch) __syncthreads();
+        sc[0].store(op.a, op.M, As, mat);
+        __syncthreads();
+        mfma_chunk(bw[0]);
+        if (ch + 1 >= chunks) break;
+        {
+            const int n2 = n_first + min(ch + 2, chunks - 1) * CL;
+            load_b(n2, bw[0]);
+            sc[0].load(op.a, op.M, n2);
+        }
+        __syncthreads();
+        sc[1].store(op.a, op.M, As, mat);
+        __syncthreads();
+        mfma_chunk(bw[1]);
     }
     reduce_store(acc, lds, op, op.out + (long)range * op.out_slab, op.K, unit * 32, nr == 1);
 }
