@@ -356,7 +356,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (BM >= 128 && BN >= 128) ? ((BM / WG
         // fused max-pool over this tile's rows (model/encoder.py:45): first row attaining the max wins
         __shared__ float smax[WGM][BN];
         __shared__ int sidx[WGM][BN];
-        const float* bias = (p.flags & HP_GEMM_BIAS) ? p.bias : nullptr;
+        const float* bias = (p.flags & HP_GEMM_BIAS) ? p.bias + (long)z * p.sBiasz : nullptr;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int cl = wn * WN + j * 32 + r;
@@ -396,8 +396,9 @@ __global__ __launch_bounds__(WGM* WGN * 64, (BM >= 128 && BN >= 128) ? ((BM / WG
                     best = smax[q][tid];
                     bi = sidx[q][tid];
                 }
-            p.cmax[(long)tile_m * p.N + col0 + tid] = best;
-            p.cidx[(long)tile_m * p.N + col0 + tid] = bi % p.group_rows;
+            // batched (z > 0: the second encoder of a pair): the partial arrays of batch z lie z*sCz elements further on
+            p.cmax[(long)z * p.sCz + (long)tile_m * p.N + col0 + tid] = best;
+            p.cidx[(long)z * p.sCz + (long)tile_m * p.N + col0 + tid] = bi % p.group_rows;
         }
         return;
     }
@@ -618,7 +619,7 @@ HP_API int hp_gemm_f32(const HpGemmDesc* d, hipStream_t stream) {
     if (d->M == 0 || d->N == 0 || d->batch == 0) return 0;
     HP_CHECK_ARG(d->A && d->B && (d->C || (d->flags & HP_GEMM_COLMAX)));
     if (d->flags & HP_GEMM_COLMAX) {
-        HP_CHECK_ARG(d->cmax && d->cidx && d->group_rows > 0 && d->batch == 1 && d->ksplit <= 1);
+        HP_CHECK_ARG(d->cmax && d->cidx && d->group_rows > 0 && d->batch >= 1 && d->ksplit <= 1);
         HP_CHECK_ARG(d->group_rows % hp_gemm_tile_rows(d) == 0 && d->M % d->group_rows == 0);
     }
     HP_CHECK_ARG(d->sAi == 1 || d->sAk == 1 || d->M == 1 || d->K == 1);

@@ -23,7 +23,8 @@ typedef struct HpGemmDesc {
     int ksplit; /* <=1: no split */
     int flags;
     /* HP_GEMM_COLMAX: rows come in groups of group_rows (one cloud); cmax/cidx are (M / tile_rows, N) with
-     * tile_rows = hp_gemm_tile_rows(desc) dividing group_rows; cidx holds the row index inside its group */
+     * tile_rows = hp_gemm_tile_rows(desc) dividing group_rows; cidx holds the row index inside its group; with batch > 1 the
+     * arrays of batch z start z*sCz elements further on */
     float* cmax;
     int* cidx;
     int group_rows;

@@ -29,6 +29,16 @@ typedef struct HpEncoderGrads {
     float* std_b;
 } HpEncoderGrads;
 
+/* One encoder's buffers for hp_encoder_forward_pair (the argument list of hp_encoder_forward as a struct). */
+typedef struct HpEncoderIO {
+    const float* x;              /* (B, Np, 3) */
+    const HpEncoderWeights* w;
+    const float* eps;            /* VAE only */
+    int* argidx;
+    float *g, *f, *mu, *lv, *z, *explv, *ws;
+    int is_vae;
+} HpEncoderIO;
+
 /* model/hyper_network.py:16-36 — trunk in->64->128->512->1024->2048, heads 2048->head_out[h] */
 typedef struct HpHyperWeights {
     const float* trunk_w[5];

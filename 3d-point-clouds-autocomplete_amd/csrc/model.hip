@@ -458,49 +458,64 @@ int sk_ranges(int contraction, int out_blocks, int smax) {
 inline long up4(long v) { return (v + 3) / 4 * 4; }
 
 
-// model/encoder.py:46-53 after the max-pool: f = ReLU(fc g) ; mu = mu_layer f ; lv = std_layer f.  Two launches (the fc
-// layer in k-ranges whose slabs the mu/std tasks finish on load, writing f on the way) instead of 3 un-split GEMMs of
-// ~19 us each.  slabs: 4*64*512 + 8*64*out_size floats.  Returns -2 when the shapes do not fit.
-int enc_tail_forward_skinny(int B, int out_size, const float* g, const HpEncoderWeights* w, int is_vae, float* f, float* mu,
-                            float* lv, float* slabs, hipStream_t stream) {
+// model/encoder.py:46-53 after the max-pool: f = ReLU(fc g) ; mu = mu_layer f ; lv = std_layer f.  Three launches (the fc
+// layer in k-ranges whose slabs the mu/std tasks finish on load, writing f on the way; the heads in k-ranges again; a
+// finishing launch) instead of 3 un-split GEMMs of ~19 us each.  n encoders (1, or the 2 of a paired forward) share the
+// launches: their ops sit in the same phases.  slabs[e]: 4*64*512 + 8*64*out_size floats.  -2: the shapes do not fit.
+struct EncTail {
+    const float* g;
+    const HpEncoderWeights* w;
+    int is_vae;
+    float *f, *mu, *lv, *slabs;
+};
+int enc_tail_forward_skinny(int B, int out_size, int n, const EncTail* t, hipStream_t stream) {
     if (B > 64 || out_size % 32) return -2;
     HpSkProgram pr{};
     const int S = sk_ranges(512, 512 / 32, 4);
-    HpSkOp& fc = pr.op[pr.nops++];
-    fc.type = HP_SK_F; fc.phase = 0;
-    fc.a.p = g; fc.a.S = 1; fc.a.ld = 512;
-    fc.w = w->fc_w; fc.w_ld = 512;
-    fc.M = B; fc.N = 512; fc.K = 512; fc.CL = 512 / S;
-    fc.out = slabs; fc.out_slab = 64L * 512; fc.out_ld = 512;
+    const int Sh = sk_ranges(512, out_size / 32, 4);
     if (S == 1) return -2;
-    HpSkSrc fsrc{};
-    fsrc.p = slabs; fsrc.slab = 64L * 512; fsrc.S = S; fsrc.ld = 512; fsrc.bias = w->fc_b; fsrc.relu = 1;
-    fsrc.mat = f; fsrc.ldmat = 512;
+    for (int e = 0; e < n; ++e) {
+        HpSkOp& fc = pr.op[pr.nops++];
+        fc.type = HP_SK_F; fc.phase = 0;
+        fc.a.p = t[e].g; fc.a.S = 1; fc.a.ld = 512;
+        fc.w = t[e].w->fc_w; fc.w_ld = 512;
+        fc.M = B; fc.N = 512; fc.K = 512; fc.CL = 512 / S;
+        fc.out = t[e].slabs; fc.out_slab = 64L * 512; fc.out_ld = 512;
+    }
     // mu / std heads: 4 strips each — k-ranges again (16 tasks of one memory latency instead of 4 tasks of eight), their
     // slabs finished by a last launch
-    const int Sh = sk_ranges(512, out_size / 32, 4);
-    float* hs = slabs + (long)S * 64 * 512;
-    for (int hd = 0; hd < (is_vae ? 2 : 1); ++hd) {
-        HpSkOp& op = pr.op[pr.nops++];
-        op.type = HP_SK_F; op.phase = 1;
-        op.a = fsrc;
-        if (hd) op.a.mat = nullptr;          // f is written once, by the mu tasks
-        op.w = hd ? w->std_w : w->mu_w; op.w_ld = 512;
-        op.M = B; op.N = out_size; op.K = 512; op.CL = 512 / Sh;
-        op.out_ld = out_size;
-        if (Sh == 1) {
-            op.out = hd ? lv : mu; op.out_bias = hd ? w->std_b : w->mu_b;
-        } else {
-            op.out = hs + (long)hd * Sh * 64 * out_size; op.out_slab = 64L * out_size;
+    for (int e = 0; e < n; ++e) {
+        const HpEncoderWeights* w = t[e].w;
+        HpSkSrc fsrc{};
+        fsrc.p = t[e].slabs; fsrc.slab = 64L * 512; fsrc.S = S; fsrc.ld = 512; fsrc.bias = w->fc_b; fsrc.relu = 1;
+        fsrc.mat = t[e].f; fsrc.ldmat = 512;
+        float* hs = t[e].slabs + (long)S * 64 * 512;
+        for (int hd = 0; hd < (t[e].is_vae ? 2 : 1); ++hd) {
+            HpSkOp& op = pr.op[pr.nops++];
+            op.type = HP_SK_F; op.phase = 1;
+            op.a = fsrc;
+            if (hd) op.a.mat = nullptr;          // f is written once, by the mu tasks
+            op.w = hd ? w->std_w : w->mu_w; op.w_ld = 512;
+            op.M = B; op.N = out_size; op.K = 512; op.CL = 512 / Sh;
+            op.out_ld = out_size;
+            if (Sh == 1) {
+                op.out = hd ? t[e].lv : t[e].mu; op.out_bias = hd ? w->std_b : w->mu_b;
+            } else {
+                op.out = hs + (long)hd * Sh * 64 * out_size; op.out_slab = 64L * out_size;
+            }
         }
     }
-    for (int hd = 0; hd < (is_vae ? 2 : 1) && Sh > 1; ++hd) {
-        HpSkOp& op = pr.op[pr.nops++];
-        op.type = HP_SK_FIN; op.phase = 2;
-        op.a.p = hs + (long)hd * Sh * 64 * out_size; op.a.slab = 64L * out_size; op.a.S = Sh; op.a.ld = out_size;
-        op.a.bias = hd ? w->std_b : w->mu_b;
-        op.out = hd ? lv : mu; op.out_ld = out_size;
-        op.M = B; op.N = out_size; op.K = 1;
+    for (int e = 0; e < n && Sh > 1; ++e) {
+        const HpEncoderWeights* w = t[e].w;
+        float* hs = t[e].slabs + (long)S * 64 * 512;
+        for (int hd = 0; hd < (t[e].is_vae ? 2 : 1); ++hd) {
+            HpSkOp& op = pr.op[pr.nops++];
+            op.type = HP_SK_FIN; op.phase = 2;
+            op.a.p = hs + (long)hd * Sh * 64 * out_size; op.a.slab = 64L * out_size; op.a.S = Sh; op.a.ld = out_size;
+            op.a.bias = hd ? w->std_b : w->mu_b;
+            op.out = hd ? t[e].lv : t[e].mu; op.out_ld = out_size;
+            op.M = B; op.N = out_size; op.K = 1;
+        }
     }
     return hp_skinny_run(&pr, stream);
 }
@@ -565,64 +580,110 @@ HP_API long hp_encoder_backward_workspace_floats(int B, int out_size) { return e
 // model/encoder.py:43-53.  x (B,Np,3) contiguous (the layout as loaded; the reference's in-place
 // transpose to (B,3,Np) is a view change only).  Outputs: argidx/g (B,512), f (B,512), mu (B,out);
 // VAE: lv (raw std_layer output), z, explv (= exp(lv), what the reference returns as "logvar").
+namespace {
+// n = 1: one encoder.  n = 2: the two encoders of a HyperPocket step (model/full_model.py:106-112: same conv stack, own
+// weights, own inputs) — every conv layer is ONE batched launch over both (z = 0, 1; strides = the distances between the
+// two encoders' buffers): twice the tiles per launch instead of two launches that each pay the ~23 us of ramp-up and
+// tail a wide GEMM launch costs (tools/pair_probe.py: 0.958 ms batched against 0.998 ms back to back and 1.004 ms on two
+// streams for the two conv stacks).  Per row the arithmetic is that of the single-encoder launch.
+int encoder_forward_impl(int B, int Np, int out_size, int n, const HpEncoderIO* io, hipStream_t stream) {
+    const long R = (long)B * Np;
+    Op op{stream, nullptr};
+    const HpEncoderIO& e0 = io[0];
+    const HpEncoderIO& e1 = io[n - 1];
+    auto dz = [&](const float* a0, const float* a1) { return n > 1 ? (long)(a1 - a0) : 0L; };
+    float* h[6];
+    h[0] = nullptr;
+    h[1] = e0.ws;
+    for (int l = 2; l <= 5; ++l) h[l] = h[l - 1] + R * kEnc[l - 1];
+    const long sWs = dz(e0.ws, e1.ws);
+    const float* in = e0.x;
+    long sIn = dz(e0.x, e1.x);
+    for (int l = 1; l <= 4; ++l) {
+        TRY(op.lin_fwd(in, sIn, kEnc[l - 1], e0.w->conv_w[l - 1], dz(e0.w->conv_w[l - 1], e1.w->conv_w[l - 1]),
+                       e0.w->conv_b[l - 1], dz(e0.w->conv_b[l - 1], e1.w->conv_b[l - 1]), h[l], sWs, kEnc[l], (int)R, kEnc[l],
+                       kEnc[l - 1], n, true));
+        in = h[l];
+        sIn = sWs;
+    }
+    // layer 5 (no ReLU) + max over points.  When a cloud's points are whole row tiles the max-pool is fused into the
+    // GEMM epilogue: h5 (B*Np x 512) is never written; its slot in the workspace holds the per-tile partials.
+    HpGemmDesc d5{};
+    d5.A = h[4]; d5.sAz = sWs; d5.sAi = 512; d5.sAk = 1;
+    d5.B = e0.w->conv_w[4]; d5.sBz = dz(e0.w->conv_w[4], e1.w->conv_w[4]); d5.sBk = 1; d5.sBj = 512;
+    d5.bias = e0.w->conv_b[4]; d5.sBiasz = dz(e0.w->conv_b[4], e1.w->conv_b[4]);
+    d5.sCz = sWs;
+    d5.M = (int)R; d5.N = 512; d5.K = 512; d5.batch = n;
+    d5.flags = HP_GEMM_BIAS | HP_GEMM_COLMAX;
+    d5.group_rows = Np;
+    const int tr = hp_gemm_tile_rows(&d5);
+    long tail_off = -1;
+    if (tr > 0 && Np % tr == 0) {
+        const long tiles = R / tr;
+        d5.cmax = h[5];
+        d5.cidx = reinterpret_cast<int*>(h[5] + tiles * 512);
+        if (R * 512 - up4(2 * tiles * 512) >= 4L * 64 * 512 + 8L * 64 * out_size) tail_off = up4(2 * tiles * 512);
+        TRY(hp_gemm_f32(&d5, stream));
+        for (int z = 0; z < n; ++z)
+            hipLaunchKernelGGL(colmax_tiles_kernel, dim3(2, B), dim3(256), 0, stream, d5.cmax + z * sWs,
+                               reinterpret_cast<int*>(d5.cmax + z * sWs + tiles * 512), Np / tr, tr, 512, io[z].g, io[z].argidx);
+    } else {
+        TRY(op.lin_fwd(h[4], sWs, 512, e0.w->conv_w[4], d5.sBz, e0.w->conv_b[4], d5.sBiasz, h[5], sWs, 512, (int)R, 512, 512, n,
+                       false));
+        for (int z = 0; z < n; ++z)
+            hipLaunchKernelGGL(colmax_kernel, dim3(512 / 64, B), dim3(256), 0, stream, h[5] + z * sWs, Np, 512, io[z].g,
+                               io[z].argidx);
+    }
+    // the fc / mu / std tails: skinny layer launches shared by the encoders when the shapes allow (the h5 slot of the
+    // workspace is free behind the fused max-pool's per-tile partials: it holds the slabs), else un-split GEMMs
+    int sk = -2;
+    if (hp_skinny_enabled() && tail_off >= 0 && B <= 64) {
+        EncTail t[2];
+        for (int z = 0; z < n; ++z) t[z] = EncTail{io[z].g, io[z].w, io[z].is_vae, io[z].f, io[z].mu, io[z].lv, h[5] + z * sWs + tail_off};
+        sk = enc_tail_forward_skinny(B, out_size, n, t, stream);
+    }
+    if (sk != -2) TRY(sk);
+    for (int z = 0; z < n; ++z) {
+        const HpEncoderIO& e = io[z];
+        if (sk == -2) {
+            TRY(op.lin_fwd(e.g, 0, 512, e.w->fc_w, 0, e.w->fc_b, 0, e.f, 0, 512, B, 512, 512, 1, true));
+            TRY(op.lin_fwd(e.f, 0, 512, e.w->mu_w, 0, e.w->mu_b, 0, e.mu, 0, out_size, B, out_size, 512, 1, false));
+            if (e.is_vae)
+                TRY(op.lin_fwd(e.f, 0, 512, e.w->std_w, 0, e.w->std_b, 0, e.lv, 0, out_size, B, out_size, 512, 1, false));
+        }
+        if (e.is_vae) {
+            const long nel = (long)B * out_size;
+            hipLaunchKernelGGL(vae_head_fwd_kernel, dim3((int)cdiv(nel, 256)), dim3(256), 0, stream, nel, e.eps, e.mu, e.lv, e.z,
+                               e.explv);
+        }
+    }
+    HP_RETURN_LAST_ERROR();
+}
+
+bool encoder_io_ok(const HpEncoderIO& e) {
+    return e.x && e.w && e.argidx && e.g && e.f && e.mu && e.ws &&
+           (!e.is_vae || (e.eps && e.lv && e.z && e.explv && e.w->std_w && e.w->std_b));
+}
+}  // namespace
+
 HP_API int hp_encoder_forward(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size, int is_vae,
                               const float* eps, int* argidx, float* g, float* f, float* mu, float* lv, float* z,
                               float* explv, float* ws, hipStream_t stream) {
     HP_CHECK_ARG(B > 0 && Np > 0 && out_size > 0 && x && w && argidx && g && f && mu && ws);
     HP_CHECK_ARG(!is_vae || (eps && lv && z && explv && w->std_w && w->std_b));
     HP_CHECK_ARG(B <= 65535);
-    const long R = (long)B * Np;
-    HP_CHECK_ARG(R < (1L << 31));
-    Op op{stream, nullptr};
-    float* h[6];
-    h[0] = nullptr;
-    h[1] = ws;
-    for (int l = 2; l <= 5; ++l) h[l] = h[l - 1] + R * kEnc[l - 1];
-    const float* in = x;
-    for (int l = 1; l <= 4; ++l) {
-        TRY(op.lin_fwd(in, 0, kEnc[l - 1], w->conv_w[l - 1], 0, w->conv_b[l - 1], 0, h[l], 0, kEnc[l], (int)R, kEnc[l],
-                       kEnc[l - 1], 1, true));
-        in = h[l];
-    }
-    // layer 5 (no ReLU) + max over points.  When a cloud's points are whole row tiles the max-pool is fused into the
-    // GEMM epilogue: h5 (B*Np x 512) is never written; its slot in the workspace holds the per-tile partials.
-    HpGemmDesc d5{};
-    d5.A = h[4]; d5.sAi = 512; d5.sAk = 1;
-    d5.B = w->conv_w[4]; d5.sBk = 1; d5.sBj = 512;
-    d5.bias = w->conv_b[4];
-    d5.M = (int)R; d5.N = 512; d5.K = 512; d5.batch = 1;
-    d5.flags = HP_GEMM_BIAS | HP_GEMM_COLMAX;
-    d5.group_rows = Np;
-    const int tr = hp_gemm_tile_rows(&d5);
-    float* tail_slabs = nullptr;
-    if (tr > 0 && Np % tr == 0) {
-        const long tiles = R / tr;
-        d5.cmax = h[5];
-        d5.cidx = reinterpret_cast<int*>(h[5] + tiles * 512);
-        if (R * 512 - up4(2 * tiles * 512) >= 4L * 64 * 512 + 8L * 64 * out_size) tail_slabs = h[5] + up4(2 * tiles * 512);
-        TRY(hp_gemm_f32(&d5, stream));
-        hipLaunchKernelGGL(colmax_tiles_kernel, dim3(2, B), dim3(256), 0, stream, d5.cmax, d5.cidx, Np / tr, tr, 512, g, argidx);
-    } else {
-        TRY(op.lin_fwd(h[4], 0, 512, w->conv_w[4], 0, w->conv_b[4], 0, h[5], 0, 512, (int)R, 512, 512, 1, false));
-        hipLaunchKernelGGL(colmax_kernel, dim3(512 / 64, B), dim3(256), 0, stream, h[5], Np, 512, g, argidx);
-    }
-    // the fc / mu / std tail: skinny layer launches when the shapes allow (the h5 slot of the workspace is free behind
-    // the fused max-pool's per-tile partials: it holds the slabs), else one un-split GEMM per layer
-    int sk = -2;
-    if (hp_skinny_enabled() && tail_slabs && B <= 64)
-        sk = enc_tail_forward_skinny(B, out_size, g, w, is_vae, f, mu, lv, tail_slabs, stream);
-    if (sk != -2) {
-        TRY(sk);
-    } else {
-        TRY(op.lin_fwd(g, 0, 512, w->fc_w, 0, w->fc_b, 0, f, 0, 512, B, 512, 512, 1, true));
-        TRY(op.lin_fwd(f, 0, 512, w->mu_w, 0, w->mu_b, 0, mu, 0, out_size, B, out_size, 512, 1, false));
-        if (is_vae) TRY(op.lin_fwd(f, 0, 512, w->std_w, 0, w->std_b, 0, lv, 0, out_size, B, out_size, 512, 1, false));
-    }
-    if (is_vae) {
-        const long n = (long)B * out_size;
-        hipLaunchKernelGGL(vae_head_fwd_kernel, dim3((int)cdiv(n, 256)), dim3(256), 0, stream, n, eps, mu, lv, z, explv);
-    }
-    HP_RETURN_LAST_ERROR();
+    HP_CHECK_ARG((long)B * Np < (1L << 31));
+    const HpEncoderIO io{x, w, eps, argidx, g, f, mu, lv, z, explv, ws, is_vae};
+    return encoder_forward_impl(B, Np, out_size, 1, &io, stream);
+}
+
+// Both encoders of a HyperPocket step in one call: io[0], io[1] as hp_encoder_forward's arguments; same B, Np, out_size.
+// The two workspaces (hp_encoder_forward_workspace_floats each) may lie anywhere; results are those of two
+// hp_encoder_forward calls.
+HP_API int hp_encoder_forward_pair(int B, int Np, int out_size, const HpEncoderIO* io, hipStream_t stream) {
+    HP_CHECK_ARG(B > 0 && Np > 0 && out_size > 0 && io && encoder_io_ok(io[0]) && encoder_io_ok(io[1]));
+    HP_CHECK_ARG(B <= 32767 && (long)B * Np < (1L << 31));
+    return encoder_forward_impl(B, Np, out_size, 2, io, stream);
 }
 
 namespace {

@@ -14,6 +14,8 @@ draws the reference takes from its RNGs.
 from itertools import chain
 from typing import Iterator
 
+import os
+
 import torch
 import torch.nn as nn
 from torch.nn import Parameter
@@ -67,6 +69,8 @@ class FullModel(nn.Module):
         # draws from the torch global generator, value for value (utils/points.py)
         self.point_sampler = 'device'
         self.concurrent_encoders = True   # HyperPocket training: run the two independent encoders on two streams
+        # ... and their conv stacks as batched launches (one node for both encoders); HP_PAIRED_ENCODERS=0: two nodes
+        self.paired_encoders = os.environ.get("HP_PAIRED_ENCODERS", "1") != "0"
         self._sampler_seed = None
         self._sampler_calls = 0
 
@@ -146,7 +150,18 @@ class HyperPocket(ModelMode):
 
     def get_latent(self, model: FullModel, existing, missing, noise=None, eps=None):
         if model.training:
-            if model.concurrent_encoders and missing.is_cuda:
+            if (model.paired_encoders and missing.is_cuda and missing.shape == existing.shape
+                    and model.random_encoder.output_size == model.real_encoder.output_size):
+                # both conv stacks as batched launches, one autograd node (ops.EncoderPairFunction)
+                from ..ops import EncoderPairFunction
+                re, pe = model.random_encoder, model.real_encoder
+                x0, x1 = missing.transpose(1, 2).contiguous(), existing.transpose(1, 2).contiguous()
+                if eps is None:
+                    eps = torch.randn((x0.size(0), re.output_size), dtype=torch.float32, device=x0.device)
+                side = _side_stream(model, missing.device) if model.concurrent_encoders else None
+                codes, mu, logvar, real_mu = EncoderPairFunction.apply(x0, eps.contiguous(), x1, re.output_size, side,
+                                                                       *re._params(), *pe._params())
+            elif model.concurrent_encoders and missing.is_cuda:
                 cur = torch.cuda.current_stream(missing.device)
                 side = _side_stream(model, missing.device)
                 side.wait_stream(cur)

@@ -194,6 +194,18 @@ long hp_encoder_forward_workspace_floats(int B, int Np);
 int hp_encoder_forward(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size, int is_vae,
                        const float* eps, int* argidx, float* g, float* f, float* mu, float* lv, float* z, float* explv,
                        float* ws, hpStream_t stream);
+/* The two encoders of a HyperPocket step (model/full_model.py:106-112: random_encoder on `missing`, real_encoder on
+ * `existing`; same conv stack, own weights) in one call: every conv layer is one batched launch over both.  io[0], io[1]
+ * carry hp_encoder_forward's arguments; same B, Np, out_size.  Results are those of two hp_encoder_forward calls. */
+typedef struct HpEncoderIO {
+    const float* x;
+    const HpEncoderWeights* w;
+    const float* eps; /* VAE only */
+    int* argidx;
+    float *g, *f, *mu, *lv, *z, *explv, *ws;
+    int is_vae;
+} HpEncoderIO;
+int hp_encoder_forward_pair(int B, int Np, int out_size, const HpEncoderIO* io /* [2] */, hpStream_t stream);
 /* Gradients of every encoder parameter (autograd of the above).  grad_out = d/dz (VAE) or d/dmu (plain);
  * grad_mu / grad_explv = direct gradients on the VAE outputs (may be NULL).  Only the 512 arg-max points of a
  * cloud carry gradient below the max-pool: their activations are copied out of fwd_ws (the workspace

@@ -501,12 +501,15 @@ def _caller_step(epoch, model, opt, batch, device, loss_fn, loss_coef=0.05):
     return loss_all.item(), loss_kld.item(), loss_r.item(), existing.detach().cpu().numpy(), rec.detach().cpu().numpy()
 
 
-def test_train_steps_vs_reference_golden():
+@pytest.mark.parametrize("paired", [True, False])
+def test_train_steps_vs_reference_golden(paired):
     """Three Adam steps of the drop-in route (FullModel + ChamferLoss + torch.optim.Adam, driven as
-    core/epoch_loops.py:15-39 drives them) vs the reference's own train_epoch."""
+    core/epoch_loops.py:15-39 drives them) vs the reference's own train_epoch — with the two encoders as one paired node
+    (batched conv launches, ops.EncoderPairFunction) and as two nodes on two streams."""
     from hyperpocket_amd.losses.champfer_loss import ChamferLoss
     g = golden("train_steps")
     model = build_model(int(g["seed"]))
+    model.paired_encoders = paired
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=0, betas=(0.9, 0.999), amsgrad=False)
     for s in range(3):
         ex, mi = torch.from_numpy(g[f"existing{s}"]), torch.from_numpy(g[f"missing{s}"])
@@ -630,6 +633,28 @@ def test_train_engine_with_emd_term_runs_and_decreases_loss():
         assert last < first
     finally:
         ops.clear_grad_views()
+
+
+def test_paired_encoders_equal_separate_encoders_bit_for_bit():
+    """hp_encoder_forward_pair batches the two conv stacks into single launches; per row the arithmetic is that of the
+    per-encoder launches: outputs and every parameter gradient of a HyperPocket forward/backward are IDENTICAL."""
+    g = torch.Generator().manual_seed(5)
+    ex, mi = (torch.rand(5, 256, 3, generator=g) - 0.5).cuda(), (torch.rand(5, 256, 3, generator=g) - 0.5).cuda()
+    pts, eps = (torch.rand(5, 512, 3, generator=g) * 2 - 1).cuda(), torch.randn(5, 128, generator=g).cuda()
+    wgt = torch.randn(5, 3, 512, generator=g).cuda()
+    res = []
+    for paired in (True, False):
+        model = build_model(2020)
+        model.paired_encoders = paired
+        rec, explv, mu = model(ex.clone(), mi.clone(), [5, 512, 3], 3, torch.device("cuda"), points=pts, eps=eps)
+        ((rec * wgt).sum() + (explv * 0.3).sum() + (mu * 0.7).sum()).backward()
+        res.append((rec.detach().clone(), explv.detach().clone(), mu.detach().clone(),
+                    {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}))
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert torch.equal(a, b)
+    assert res[0][3].keys() == res[1][3].keys()
+    for k in res[0][3]:
+        assert torch.equal(res[0][3][k], res[1][3][k]), k
 
 
 def test_train_engine_steps_are_bit_identical_run_to_run():

@@ -5,6 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 B=/root/repo/bench.py
 python3 $B > $O/bench_n1.json 2> $O/bench_n1.err
 python3 $B --no-emd --no-cpu-baseline > $O/bench_chamfer.json 2>/dev/null
+python3 $B --batch 32 --no-cpu-baseline --no-extras > $O/bench_b32.json 2>/dev/null   # BASELINE configs[1]: B=32, N=2048, Chamfer+EMD on one GPU
 python3 $B --workload chamfer-stress > $O/bench_stress.json 2>/dev/null
 python3 $B --roofline-only > $O/roofline_events.json 2>/dev/null
 prof() { d=$1; shift; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$d -- python3 $B "$@" > $O/$d.log 2>&1; }

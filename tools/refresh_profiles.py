@@ -30,6 +30,7 @@ def one(d, substr):
 
 
 for src, dst in (("bench_n1.json", "bench_n1.json"), ("bench_chamfer.json", "bench_n1_chamfer_only.json"),
+                 ("bench_b32.json", "bench_n1_b32_config1.json"),
                  ("bench_stress.json", "bench_chamfer_stress_n8192.json"), ("roofline_events.json", "roofline_hip_events.txt")):
     shutil.copy(os.path.join(F, src), os.path.join(P, f"{RD}_{dst}"))
 summ = os.path.join(R, "tools", "summarize_profile.py")
