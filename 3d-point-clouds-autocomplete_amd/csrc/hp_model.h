@@ -37,6 +37,8 @@ typedef struct HpEncoderIO {
     int* argidx;
     float *g, *f, *mu, *lv, *z, *explv, *ws;
     int is_vae;
+    int out_ld; /* row stride of the primary output (z of a VAE encoder, mu of a plain one); 0 = out_size (dense).  The two
+                   encoders of a pair can so write the halves of one (B, 2*out) latent [z | real mu] directly */
 } HpEncoderIO;
 
 /* model/hyper_network.py:16-36 — trunk in->64->128->512->1024->2048, heads 2048->head_out[h] */

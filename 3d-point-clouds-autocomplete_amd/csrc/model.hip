@@ -415,24 +415,25 @@ __global__ __launch_bounds__(512) void enc_l5_bwd_kernel(int B, int C, int K, co
 }
 
 // VAE head (model/encoder.py:38-41,49-51): z = eps*exp(lv) + mu ; returned "logvar" = exp(lv)
+// z may be a column block of a wider matrix (the latent [z | real mu] of a paired forward): row stride z_ld, `out` columns
 __global__ __launch_bounds__(256) void vae_head_fwd_kernel(long n, const float* __restrict__ eps, const float* __restrict__ mu,
-                                                           const float* __restrict__ lv, float* __restrict__ z,
+                                                           const float* __restrict__ lv, float* __restrict__ z, int out, int z_ld,
                                                            float* __restrict__ explv) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     if (t >= n) return;
     const float e = expf(lv[t]);   // accurate exp: z and the returned exp(logvar) are parity outputs
     explv[t] = e;
-    z[t] = __builtin_fmaf(eps[t], e, mu[t]);
+    z[(t / out) * z_ld + t % out] = __builtin_fmaf(eps[t], e, mu[t]);
 }
 
 // d mu = gz + gmu ; d lv = (gz*eps + gexplv) * exp(lv)
 __global__ __launch_bounds__(256) void vae_head_bwd_kernel(long n, const float* __restrict__ eps, const float* __restrict__ lv,
-                                                           const float* __restrict__ gz, const float* __restrict__ gmu,
-                                                           const float* __restrict__ gexplv, float* __restrict__ dmu,
-                                                           float* __restrict__ dlv) {
+                                                           const float* __restrict__ gz, int out, int gz_ld,
+                                                           const float* __restrict__ gmu, const float* __restrict__ gexplv,
+                                                           float* __restrict__ dmu, float* __restrict__ dlv) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     if (t >= n) return;
-    const float a = gz ? gz[t] : 0.f;
+    const float a = gz ? gz[(t / out) * gz_ld + t % out] : 0.f;
     dmu[t] = a + (gmu ? gmu[t] : 0.f);
     dlv[t] = (a * eps[t] + (gexplv ? gexplv[t] : 0.f)) * expf(lv[t]);
 }
@@ -467,6 +468,7 @@ struct EncTail {
     const HpEncoderWeights* w;
     int is_vae;
     float *f, *mu, *lv, *slabs;
+    int mu_ld;   // row stride of mu (a plain encoder's mu may be a column block of the latent)
 };
 int enc_tail_forward_skinny(int B, int out_size, int n, const EncTail* t, hipStream_t stream) {
     if (B > 64 || out_size % 32) return -2;
@@ -500,6 +502,7 @@ int enc_tail_forward_skinny(int B, int out_size, int n, const EncTail* t, hipStr
             op.out_ld = out_size;
             if (Sh == 1) {
                 op.out = hd ? t[e].lv : t[e].mu; op.out_bias = hd ? w->std_b : w->mu_b;
+                if (!hd) op.out_ld = t[e].mu_ld;
             } else {
                 op.out = hs + (long)hd * Sh * 64 * out_size; op.out_slab = 64L * out_size;
             }
@@ -513,7 +516,7 @@ int enc_tail_forward_skinny(int B, int out_size, int n, const EncTail* t, hipStr
             op.type = HP_SK_FIN; op.phase = 2;
             op.a.p = hs + (long)hd * Sh * 64 * out_size; op.a.slab = 64L * out_size; op.a.S = Sh; op.a.ld = out_size;
             op.a.bias = hd ? w->std_b : w->mu_b;
-            op.out = hd ? t[e].lv : t[e].mu; op.out_ld = out_size;
+            op.out = hd ? t[e].lv : t[e].mu; op.out_ld = hd ? out_size : t[e].mu_ld;
             op.M = B; op.N = out_size; op.K = 1;
         }
     }
@@ -523,7 +526,7 @@ int enc_tail_forward_skinny(int B, int out_size, int n, const EncTail* t, hipStr
 // the autograd of that tail: dmu (and dlv) -> d mu_w/b, d std_w/b, dfc = (dmu mu_w + dlv std_w) * (f > 0), d fc_w/b,
 // dg = dfc fc_w.  Three launches instead of 7-8.  slabs: 8*64*512 floats.
 int enc_tail_backward_skinny(int B, int out_size, const float* g, const float* f, const HpEncoderWeights* w, const float* dmu,
-                             const float* dlv, const HpEncoderGrads* gr, float* dfc, float* dg, float* slabs,
+                             int dmu_ld, const float* dlv, const HpEncoderGrads* gr, float* dfc, float* dg, float* slabs,
                              hipStream_t stream) {
     if (B > 64 || out_size % 32) return -2;
     HpSkProgram pr{};
@@ -532,7 +535,7 @@ int enc_tail_backward_skinny(int B, int out_size, const float* g, const float* f
     for (int hd = 0; hd < nh; ++hd) {
         HpSkOp& op = pr.op[pr.nops++];
         op.type = HP_SK_X; op.phase = 0;
-        op.a.p = hd ? dlv : dmu; op.a.S = 1; op.a.ld = out_size;
+        op.a.p = hd ? dlv : dmu; op.a.S = 1; op.a.ld = hd ? out_size : dmu_ld;
         op.w = hd ? w->std_w : w->mu_w; op.w_ld = 512;
         op.M = B; op.N = out_size; op.K = 512; op.CL = out_size / S;
         op.out = slabs + (long)hd * S * 64 * 512; op.out_slab = 64L * 512; op.out_ld = 512;
@@ -541,7 +544,7 @@ int enc_tail_backward_skinny(int B, int out_size, const float* g, const float* f
     for (int hd = 0; hd < nh; ++hd) {
         HpSkOp& op = pr.op[pr.nops++];
         op.type = HP_SK_W; op.phase = 0;
-        op.a.p = hd ? dlv : dmu; op.a.S = 1; op.a.ld = out_size;
+        op.a.p = hd ? dlv : dmu; op.a.S = 1; op.a.ld = hd ? out_size : dmu_ld;
         op.w = f; op.w_ld = 512;
         op.out = hd ? gr->std_w : gr->mu_w; op.out_ld = 512; op.rsum = hd ? gr->std_b : gr->mu_b;
         op.M = B; op.N = out_size; op.K = 512;
@@ -639,7 +642,8 @@ int encoder_forward_impl(int B, int Np, int out_size, int n, const HpEncoderIO* 
     int sk = -2;
     if (hp_skinny_enabled() && tail_off >= 0 && B <= 64) {
         EncTail t[2];
-        for (int z = 0; z < n; ++z) t[z] = EncTail{io[z].g, io[z].w, io[z].is_vae, io[z].f, io[z].mu, io[z].lv, h[5] + z * sWs + tail_off};
+        for (int z = 0; z < n; ++z) t[z] = EncTail{io[z].g, io[z].w, io[z].is_vae, io[z].f, io[z].mu, io[z].lv, h[5] + z * sWs + tail_off,
+                           (!io[z].is_vae && io[z].out_ld > 0) ? io[z].out_ld : out_size};
         sk = enc_tail_forward_skinny(B, out_size, n, t, stream);
     }
     if (sk != -2) TRY(sk);
@@ -647,14 +651,15 @@ int encoder_forward_impl(int B, int Np, int out_size, int n, const HpEncoderIO* 
         const HpEncoderIO& e = io[z];
         if (sk == -2) {
             TRY(op.lin_fwd(e.g, 0, 512, e.w->fc_w, 0, e.w->fc_b, 0, e.f, 0, 512, B, 512, 512, 1, true));
-            TRY(op.lin_fwd(e.f, 0, 512, e.w->mu_w, 0, e.w->mu_b, 0, e.mu, 0, out_size, B, out_size, 512, 1, false));
+            TRY(op.lin_fwd(e.f, 0, 512, e.w->mu_w, 0, e.w->mu_b, 0, e.mu, 0, (!e.is_vae && e.out_ld > 0) ? e.out_ld : out_size, B,
+                           out_size, 512, 1, false));
             if (e.is_vae)
                 TRY(op.lin_fwd(e.f, 0, 512, e.w->std_w, 0, e.w->std_b, 0, e.lv, 0, out_size, B, out_size, 512, 1, false));
         }
         if (e.is_vae) {
             const long nel = (long)B * out_size;
             hipLaunchKernelGGL(vae_head_fwd_kernel, dim3((int)cdiv(nel, 256)), dim3(256), 0, stream, nel, e.eps, e.mu, e.lv, e.z,
-                               e.explv);
+                               out_size, e.out_ld > 0 ? e.out_ld : out_size, e.explv);
         }
     }
     HP_RETURN_LAST_ERROR();
@@ -673,7 +678,7 @@ HP_API int hp_encoder_forward(int B, int Np, const float* x, const HpEncoderWeig
     HP_CHECK_ARG(!is_vae || (eps && lv && z && explv && w->std_w && w->std_b));
     HP_CHECK_ARG(B <= 65535);
     HP_CHECK_ARG((long)B * Np < (1L << 31));
-    const HpEncoderIO io{x, w, eps, argidx, g, f, mu, lv, z, explv, ws, is_vae};
+    const HpEncoderIO io{x, w, eps, argidx, g, f, mu, lv, z, explv, ws, is_vae, 0};
     return encoder_forward_impl(B, Np, out_size, 1, &io, stream);
 }
 
@@ -775,11 +780,25 @@ static int enc_critical_rows(int B, int Np, const float* x, const HpEncoderWeigh
 // hp_encoder_forward ran in, untouched since (NULL: recompute the critical rows' activations instead).
 // dedup != 0: channels that peak at the same point share one row below the max-pool (their gradients add): layers 4..1
 // run on the DISTINCT critical points (~1/3 of B*512), a count that stays on the device.
+HP_API int hp_encoder_backward_ld(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size, int is_vae,
+                                  const float* eps, const int* argidx, const float* g, const float* f, const float* lv,
+                                  const float* grad_out, int grad_out_ld, const float* grad_mu, const float* grad_explv,
+                                  const HpEncoderGrads* gr, float* ws, const float* fwd_ws, int dedup, hipStream_t stream);
 HP_API int hp_encoder_backward(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size, int is_vae,
                                const float* eps, const int* argidx, const float* g, const float* f, const float* lv,
                                const float* grad_out, const float* grad_mu, const float* grad_explv,
                                const HpEncoderGrads* gr, float* ws, const float* fwd_ws, int dedup, hipStream_t stream) {
-    HP_CHECK_ARG(B > 0 && Np > 0 && out_size > 0 && x && w && argidx && g && f && gr && ws);
+    return hp_encoder_backward_ld(B, Np, x, w, out_size, is_vae, eps, argidx, g, f, lv, grad_out, out_size, grad_mu, grad_explv, gr, ws,
+                                  fwd_ws, dedup, stream);
+}
+// ... with grad_out a column block of a wider matrix (row stride grad_out_ld >= out_size: the paired forward's latent
+// [z | real mu] hands each encoder its half of d latent without a copy)
+HP_API int hp_encoder_backward_ld(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size, int is_vae,
+                                  const float* eps, const int* argidx, const float* g, const float* f, const float* lv,
+                                  const float* grad_out, int grad_out_ld, const float* grad_mu, const float* grad_explv,
+                                  const HpEncoderGrads* gr, float* ws, const float* fwd_ws, int dedup, hipStream_t stream) {
+    HP_CHECK_ARG(B > 0 && Np > 0 && out_size > 0 && x && w && argidx && g && f && gr && ws && grad_out_ld >= out_size);
+    const int gld = grad_out_ld;
     HP_CHECK_ARG(grad_out || grad_mu || grad_explv);
     HP_CHECK_ARG(!is_vae || (eps && lv));
     const long Rc = (long)B * 512;
@@ -796,15 +815,16 @@ HP_API int hp_encoder_backward(int B, int Np, const float* x, const HpEncoderWei
     const float* dmu_p;
     if (is_vae) {
         const long n = (long)B * out_size;
-        hipLaunchKernelGGL(vae_head_bwd_kernel, dim3((int)cdiv(n, 256)), dim3(256), 0, stream, n, eps, lv, grad_out, grad_mu,
-                           grad_explv, dmu, dlv);
+        hipLaunchKernelGGL(vae_head_bwd_kernel, dim3((int)cdiv(n, 256)), dim3(256), 0, stream, n, eps, lv, grad_out, out_size,
+                           gld, grad_mu, grad_explv, dmu, dlv);
         dmu_p = dmu;
     } else {
         dmu_p = grad_out;
     }
+    const int dmu_ld = is_vae ? out_size : gld;
     int sk = -2;
-    if (hp_skinny_enabled() && B <= 64 && dmu_p)
-        sk = enc_tail_backward_skinny(B, out_size, g, f, w, dmu_p, is_vae ? dlv : nullptr, gr, dfc, dg, L.split, stream);
+    if (hp_skinny_enabled() && B <= 64 && dmu_p && dmu_ld % 4 == 0)
+        sk = enc_tail_backward_skinny(B, out_size, g, f, w, dmu_p, dmu_ld, is_vae ? dlv : nullptr, gr, dfc, dg, L.split, stream);
     if (sk != -2) {
         TRY(sk);
     } else {
@@ -812,8 +832,8 @@ HP_API int hp_encoder_backward(int B, int Np, const float* x, const HpEncoderWei
             TRY(op.lin_dw(dlv, 0, out_size, f, 0, 512, gr->std_w, 0, B, out_size, 512, 1, gr->std_b));
             TRY(op.lin_dx(dlv, 0, out_size, w->std_w, 0, tmp, 0, 512, B, out_size, 512, 1, nullptr, 0, 0, nullptr, 0));
         }
-        TRY(op.lin_dw(dmu_p, 0, out_size, f, 0, 512, gr->mu_w, 0, B, out_size, 512, 1, gr->mu_b));
-        TRY(op.lin_dx(dmu_p, 0, out_size, w->mu_w, 0, dfc, 0, 512, B, out_size, 512, 1, f, 0, 512, is_vae ? tmp : nullptr, 512));
+        TRY(op.lin_dw(dmu_p, 0, dmu_ld, f, 0, 512, gr->mu_w, 0, B, out_size, 512, 1, gr->mu_b));
+        TRY(op.lin_dx(dmu_p, 0, dmu_ld, w->mu_w, 0, dfc, 0, 512, B, out_size, 512, 1, f, 0, 512, is_vae ? tmp : nullptr, 512));
         TRY(op.lin_dw(dfc, 0, 512, g, 0, 512, gr->fc_w, 0, B, 512, 512, 1, gr->fc_b));
         TRY(op.lin_dx(dfc, 0, 512, w->fc_w, 0, dg, 0, 512, B, 512, 512, 1, nullptr, 0, 0, nullptr, 0));
     }

@@ -159,8 +159,9 @@ class HyperPocket(ModelMode):
                 if eps is None:
                     eps = torch.randn((x0.size(0), re.output_size), dtype=torch.float32, device=x0.device)
                 side = _side_stream(model, missing.device) if model.concurrent_encoders else None
-                codes, mu, logvar, real_mu = EncoderPairFunction.apply(x0, eps.contiguous(), x1, re.output_size, side,
-                                                                       *re._params(), *pe._params())
+                latent, mu, logvar = EncoderPairFunction.apply(x0, eps.contiguous(), x1, re.output_size, side,
+                                                               *re._params(), *pe._params())
+                return latent, mu, logvar                    # latent = [codes | real_mu], written in place by the two encoders
             elif model.concurrent_encoders and missing.is_cuda:
                 cur = torch.cuda.current_stream(missing.device)
                 side = _side_stream(model, missing.device)

@@ -22,7 +22,7 @@ class _EncoderPtrs(ctypes.Structure):  # HpEncoderWeights / HpEncoderGrads (csrc
 class _EncoderIO(ctypes.Structure):  # HpEncoderIO (one encoder's buffers for hp_encoder_forward_pair)
     _fields_ = [("x", c_void_p), ("w", ctypes.POINTER(_EncoderPtrs)), ("eps", c_void_p), ("argidx", c_void_p),
                 ("g", c_void_p), ("f", c_void_p), ("mu", c_void_p), ("lv", c_void_p), ("z", c_void_p), ("explv", c_void_p),
-                ("ws", c_void_p), ("is_vae", c_int)]
+                ("ws", c_void_p), ("is_vae", c_int), ("out_ld", c_int)]
 
 
 class _HyperWeights(ctypes.Structure):  # HpHyperWeights
@@ -155,7 +155,8 @@ class EncoderPairFunction(Function):
     """The two encoders of a HyperPocket training step (model/full_model.py:106-112) as ONE node: the conv stacks of both run
     as batched launches (hp_encoder_forward_pair); the backward runs the two independent hp_encoder_backward chains on two
     streams.  Arguments: x_vae (missing), eps, x_plain (existing), out_size, side stream, then the VAE encoder's 16
-    parameters and the plain encoder's 14.  Returns (z, mu, exp(logvar), real_mu)."""
+    parameters and the plain encoder's 14.  Returns (latent, mu, exp(logvar)) with latent = [z | real_mu] (B, 2*out): the two
+    encoders write its halves directly (no torch.cat) and the backward reads the halves of d latent in place."""
 
     N_VAE = 16
 
@@ -175,29 +176,33 @@ class EncoderPairFunction(Function):
         nws = _long_fn("hp_encoder_forward_workspace_floats", B, Np)
         io = (_EncoderIO * 2)()
         keep, structs = [], []
+        latent = torch.empty((B, 2 * out_size), **f32)
         for e, (x, ps, vae) in enumerate(((x0, p0, True), (x1, p1, False))):
             argidx = torch.empty((B, 512), dtype=torch.int32, device=dev)
             g, f = torch.empty((B, 512), **f32), torch.empty((B, 512), **f32)
-            mu = torch.empty((B, out_size), **f32)
             lv = z = explv = None
             if vae:
-                lv, z, explv = (torch.empty((B, out_size), **f32) for _ in range(3))
+                mu = torch.empty((B, out_size), **f32)
+                lv, explv = (torch.empty((B, out_size), **f32) for _ in range(2))
+                z = latent                                   # columns [0, out)
+            else:
+                mu = latent[:, out_size:]                    # columns [out, 2*out): data_ptr() is the block's first element
             ws = torch.empty((nws,), **f32)
             w = _encoder_struct(ps)
             structs.append(w)
             io[e].x, io[e].w, io[e].eps, io[e].argidx = x.data_ptr(), ctypes.pointer(w), _dp(eps if vae else None), argidx.data_ptr()
             io[e].g, io[e].f, io[e].mu, io[e].lv, io[e].z, io[e].explv = (_dp(t) for t in (g, f, mu, lv, z, explv))
-            io[e].ws, io[e].is_vae = ws.data_ptr(), int(vae)
+            io[e].ws, io[e].is_vae, io[e].out_ld = ws.data_ptr(), int(vae), 2 * out_size
             keep.append((argidx, g, f, mu, lv, z, explv, ws))
         call("hp_encoder_forward_pair", B, Np, out_size, io, current_stream(dev))
         ctx.out_size, ctx.side = out_size, side
         ctx.fwd_ws = [k[7] if KEEP_ENCODER_ACTIVATIONS else None for k in keep]
         ctx.save_for_backward(x0, eps, x1, keep[0][0], keep[0][1], keep[0][2], keep[0][4], keep[1][0], keep[1][1], keep[1][2],
                               *params)
-        return keep[0][5], keep[0][3], keep[0][6], keep[1][3]
+        return latent, keep[0][3], keep[0][6]
 
     @staticmethod
-    def backward(ctx, gz, gmu, gexplv, greal):
+    def backward(ctx, glat, gmu, gexplv):
         x0, eps, x1, arg0, g0, f0, lv0, arg1, g1, f1, *params = ctx.saved_tensors
         p0, p1 = params[:EncoderPairFunction.N_VAE], params[EncoderPairFunction.N_VAE:]
         B, Np = x0.size(0), x0.size(1)
@@ -205,24 +210,28 @@ class EncoderPairFunction(Function):
         cur = torch.cuda.current_stream(dev)
         side = ctx.side if ctx.side is not None else cur
         nws = _long_fn("hp_encoder_backward_workspace_floats", B, ctx.out_size)
-        gz, gmu, gexplv = (None if t is None else t.contiguous() for t in (gz, gmu, gexplv))
+        glat, gmu, gexplv = (None if t is None else t.contiguous() for t in (glat, gmu, gexplv))
+        if glat is None:
+            glat = torch.zeros((B, 2 * ctx.out_size), dtype=torch.float32, device=dev)
         out0, out1 = [_grad_buffer(p) for p in p0], [_grad_buffer(p) for p in p1]
+        gz, greal = glat, glat[:, ctx.out_size:]             # the halves of d latent, read in place (row stride 2*out)
 
         def run(x, ps, outs, vae, argidx, g, f, lv, gout, gm, ge, fwd_ws):
             ws = torch.empty((nws,), dtype=torch.float32, device=dev)
             w, gr = _encoder_struct(ps), _encoder_struct(outs)
-            call("hp_encoder_backward", B, Np, x, ctypes.byref(w), ctx.out_size, int(vae), eps if vae else None, argidx, g, f,
-                 lv, gout, gm, ge, ctypes.byref(gr), ws, fwd_ws, int(DEDUP_CRITICAL_ROWS), current_stream(dev))
+            call("hp_encoder_backward_ld", B, Np, x, ctypes.byref(w), ctx.out_size, int(vae), eps if vae else None, argidx, g,
+                 f, lv, ctypes.c_void_p(gout.data_ptr()), 2 * ctx.out_size, gm, ge, ctypes.byref(gr), ws, fwd_ws,
+                 int(DEDUP_CRITICAL_ROWS), current_stream(dev))
 
         # the two chains are independent (~17 small launches each): the VAE encoder's goes to the side stream
         if side is not cur:
             side.wait_stream(cur)
         with torch.cuda.stream(side):
             run(x0, p0, out0, True, arg0, g0, f0, lv0, gz, gmu, gexplv, ctx.fwd_ws[0])
-        run(x1, p1, out1, False, arg1, g1, f1, None, greal.contiguous(), None, None, ctx.fwd_ws[1])
+        run(x1, p1, out1, False, arg1, g1, f1, None, greal, None, None, ctx.fwd_ws[1])
         if side is not cur:
             cur.wait_stream(side)
-            for t in (gz, gmu, gexplv):
+            for t in (glat, gmu, gexplv):
                 if t is not None:
                     t.record_stream(side)
         ctx.fwd_ws = None

@@ -204,6 +204,8 @@ typedef struct HpEncoderIO {
     int* argidx;
     float *g, *f, *mu, *lv, *z, *explv, *ws;
     int is_vae;
+    int out_ld; /* row stride of the primary output (z of a VAE encoder, mu of a plain one); 0 = out_size (dense).  The two
+                   encoders of a pair can so write the halves of one (B, 2*out) latent [z | real mu] directly */
 } HpEncoderIO;
 int hp_encoder_forward_pair(int B, int Np, int out_size, const HpEncoderIO* io /* [2] */, hpStream_t stream);
 /* Gradients of every encoder parameter (autograd of the above).  grad_out = d/dz (VAE) or d/dmu (plain);
@@ -217,6 +219,11 @@ int hp_encoder_backward(int B, int Np, const float* x, const HpEncoderWeights* w
                         const float* eps, const int* argidx, const float* g, const float* f, const float* lv,
                         const float* grad_out, const float* grad_mu, const float* grad_explv, const HpEncoderGrads* grads,
                         float* ws, const float* fwd_ws, int dedup, hpStream_t stream);
+/* ... with grad_out a column block of a wider matrix (row stride grad_out_ld >= out_size). */
+int hp_encoder_backward_ld(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size, int is_vae,
+                           const float* eps, const int* argidx, const float* g, const float* f, const float* lv,
+                           const float* grad_out, int grad_out_ld, const float* grad_mu, const float* grad_explv,
+                           const HpEncoderGrads* grads, float* ws, const float* fwd_ws, int dedup, hpStream_t stream);
 
 /* HyperNetwork.forward (model/hyper_network.py:41-43): latent (B,in) -> theta (B,theta_ld); t = saved trunk
  * activations (hp_hypernet_saved_floats floats) for the backward. */
