@@ -156,6 +156,7 @@ class TrainEngine:
         self.steps = 0             # completed optimisation steps
         self._adam_step = 0        # the step number the Adam launches of the step in flight use (bias correction)
         self._heads_pending = False
+        self._deferred_losses = None
         model._pre_hypernet_hook = self.finish_pending     # FullModel.forward calls it right before the hypernetwork
         # A reader of the parameters outside `step` (model.state_dict(), torch.save: core/main.py:164) must not see the
         # hypernetwork one step behind the encoders or half-gathered rows: flush the deferred updates first.
@@ -214,6 +215,9 @@ class TrainEngine:
             torch.autograd.backward(roots, root_grads)
         finally:
             ops.HEADS_DW_EXCHANGE = None
+            args, self._deferred_losses = self._deferred_losses, None
+            if args is not None:
+                call("hp_step_losses", *args, current_stream(device))
         self.steps = self._adam_step
         # Exchange + update per bucket.  The encoders' bucket (6.6 MB) is reduced and updated now: the next step starts
         # with it.  The hypernetwork's buckets (heads 156 MB, trunk 11 MB: 96 % of the bytes) are only needed again in the
@@ -310,7 +314,9 @@ class TrainEngine:
             cur.wait_stream(side)
             g_rec.add_(g_emd, alpha=c_emd)
         terms = torch.empty((4,), **f32)
-        call("hp_step_losses", B, cd, kld, cost, float(self.loss_coef), c_emd, terms, current_stream(dev))
+        # the scalar loss terms are nobody's input: their launch is deferred behind the backward's launches (step()), so it
+        # does not sit between the EMD and the first backward kernel
+        self._deferred_losses = (B, cd, kld, cost, float(self.loss_coef), c_emd, terms)
         out = {"loss_r": terms[0], "loss_all": terms[3]}
         if has_kld:
             out["loss_kld"] = terms[1]
