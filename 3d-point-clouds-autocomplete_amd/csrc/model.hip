@@ -308,23 +308,26 @@ __global__ __launch_bounds__(256) void crit_offsets_kernel(int B, Crit c) {
     }
 }
 
-// One workgroup per (cloud, slot): the distinct critical point's x, h1, h2, h3 out of the forward's per-point arrays
-// into compact row off[b] + slot (16-byte accesses).  h1 == NULL: coordinates only (the recompute path).
+// One WAVE per (cloud, slot), four slots per workgroup: the distinct critical point's x, h1, h2, h3 out of the forward's
+// per-point arrays into compact row off[b] + slot (16-byte accesses: 112 per slot in two passes of the wave).
+// h1 == NULL: coordinates only (the recompute path).  (One 256-thread workgroup per slot — 32768 launches of which a third
+// are live and 112 threads work — was bound by workgroup dispatch: 21 us.)
 __global__ __launch_bounds__(256) void crit_gather_kernel(int Np, Crit c, const float* __restrict__ x, const float* __restrict__ h1,
                                                           const float* __restrict__ h2, const float* __restrict__ h3,
                                                           float* __restrict__ xc, float* __restrict__ c1,
                                                           float* __restrict__ c2, float* __restrict__ c3) {
-    const int b = blockIdx.x >> 9, u = blockIdx.x & 511;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = slot >> 9, u = slot & 511;
     if (u >= c.cnt[b]) return;
     const long t = c.off[b] + u;
     const long src = (long)b * Np + c.pt[(long)b * 512 + u];
-    const int i = threadIdx.x;
+    const int i = threadIdx.x & 63;
     if (h1) {
+        reinterpret_cast<float4*>(c3 + t * 256)[i] = reinterpret_cast<const float4*>(h3 + src * 256)[i];
         if (i < 16) reinterpret_cast<float4*>(c1 + t * 64)[i] = reinterpret_cast<const float4*>(h1 + src * 64)[i];
         else if (i < 48) reinterpret_cast<float4*>(c2 + t * 128)[i - 16] = reinterpret_cast<const float4*>(h2 + src * 128)[i - 16];
-        else if (i < 112) reinterpret_cast<float4*>(c3 + t * 256)[i - 48] = reinterpret_cast<const float4*>(h3 + src * 256)[i - 48];
     }
-    if (i >= 240 && i < 243) xc[t * 3 + (i - 240)] = x[src * 3 + (i - 240)];
+    if (i >= 48 && i < 51) xc[t * 3 + (i - 48)] = x[src * 3 + (i - 48)];
 }
 
 // delta4 of a distinct critical point = (its h4 > 0) * sum over the channels that peak there of dg[b,c] * W5[c,:], channels
@@ -741,7 +744,7 @@ static int enc_critical_rows(int B, int Np, const float* x, const HpEncoderWeigh
         const float* h1 = fwd_ws;
         const float* h2 = fwd_ws ? h1 + R * 64 : nullptr;
         const float* h3 = fwd_ws ? h2 + R * 128 : nullptr;
-        hipLaunchKernelGGL(crit_gather_kernel, dim3((unsigned)Rc), dim3(256), 0, stream, Np, L.crit, x, h1, h2, h3, L.xc, L.hc[1],
+        hipLaunchKernelGGL(crit_gather_kernel, dim3((unsigned)(Rc / 4)), dim3(256), 0, stream, Np, L.crit, x, h1, h2, h3, L.xc, L.hc[1],
                            L.hc[2], L.hc[3]);
         if (!fwd_ws) {
             Op op{stream, nullptr, L.crit.total};
