@@ -169,10 +169,18 @@ __global__ __launch_bounds__(256) void colmax_kernel(const float* __restrict__ h
 }
 
 // second stage of the fused max-pool: g[b,c] = max over the cloud's row tiles (ascending, strict >: first row wins)
+// blockIdx.z = 1: the second encoder of a paired forward (its partials lie zstride floats further on, its outputs are g1/arg1)
 __global__ __launch_bounds__(256) void colmax_tiles_kernel(const float* __restrict__ pm, const int* __restrict__ pi, int tiles,
-                                                           int tile_rows, int C, float* __restrict__ g, int* __restrict__ arg) {
+                                                           int tile_rows, int C, float* __restrict__ g, int* __restrict__ arg,
+                                                           long zstride, float* __restrict__ g1, int* __restrict__ arg1) {
     const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
+    if (blockIdx.z) {
+        pm += zstride;
+        pi += zstride;
+        g = g1;
+        arg = arg1;
+    }
     const long base = (long)b * tiles * C + c;
     float best = pm[base];
     int bi = pi[base];
@@ -630,9 +638,8 @@ int encoder_forward_impl(int B, int Np, int out_size, int n, const HpEncoderIO* 
         d5.cidx = reinterpret_cast<int*>(h[5] + tiles * 512);
         if (R * 512 - up4(2 * tiles * 512) >= 4L * 64 * 512 + 8L * 64 * out_size) tail_off = up4(2 * tiles * 512);
         TRY(hp_gemm_f32(&d5, stream));
-        for (int z = 0; z < n; ++z)
-            hipLaunchKernelGGL(colmax_tiles_kernel, dim3(2, B), dim3(256), 0, stream, d5.cmax + z * sWs,
-                               reinterpret_cast<int*>(d5.cmax + z * sWs + tiles * 512), Np / tr, tr, 512, io[z].g, io[z].argidx);
+        hipLaunchKernelGGL(colmax_tiles_kernel, dim3(2, B, n), dim3(256), 0, stream, d5.cmax, d5.cidx, Np / tr, tr, 512, io[0].g,
+                           io[0].argidx, sWs, io[n - 1].g, io[n - 1].argidx);
     } else {
         TRY(op.lin_fwd(h[4], sWs, 512, e0.w->conv_w[4], d5.sBz, e0.w->conv_b[4], d5.sBiasz, h[5], sWs, 512, (int)R, 512, 512, n,
                        false));
