@@ -291,45 +291,31 @@ __global__ __launch_bounds__(512) void crit_unique_kernel(const int* __restrict_
     }
 }
 
-// off = exclusive prefix sum of cnt over the clouds, total = its end (one workgroup; chunked scan)
-__global__ __launch_bounds__(256) void crit_offsets_kernel(int B, Crit c) {
-    __shared__ int part[256];
-    const int t = threadIdx.x, per = (B + 255) / 256, lo = min(B, t * per), hi = min(B, lo + per);
-    int s = 0;
-    for (int b = lo; b < hi; ++b) s += c.cnt[b];
-    part[t] = s;
-    __syncthreads();
-    if (t == 0) {
-        int run = 0;
-        for (int i = 0; i < 256; ++i) {
-            const int v = part[i];
-            part[i] = run;
-            run += v;
-        }
-        c.total[0] = run;
-    }
-    __syncthreads();
-    int run = part[t];
-    for (int b = lo; b < hi; ++b) {
-        c.off[b] = run;
-        run += c.cnt[b];
-    }
-}
-
 // One WAVE per (cloud, slot), four slots per workgroup: the distinct critical point's x, h1, h2, h3 out of the forward's
 // per-point arrays into compact row off[b] + slot (16-byte accesses: 112 per slot in two passes of the wave).
 // h1 == NULL: coordinates only (the recompute path).  (One 256-thread workgroup per slot — 32768 launches of which a third
 // are live and 112 threads work — was bound by workgroup dispatch: 21 us.)
-__global__ __launch_bounds__(256) void crit_gather_kernel(int Np, Crit c, const float* __restrict__ x, const float* __restrict__ h1,
+__global__ __launch_bounds__(256) void crit_gather_kernel(int B, int Np, Crit c, const float* __restrict__ x, const float* __restrict__ h1,
                                                           const float* __restrict__ h2, const float* __restrict__ h3,
                                                           float* __restrict__ xc, float* __restrict__ c1,
                                                           float* __restrict__ c2, float* __restrict__ c3) {
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int b = slot >> 9, u = slot & 511;
     if (u >= c.cnt[b]) return;
-    const long t = c.off[b] + u;
-    const long src = (long)b * Np + c.pt[(long)b * 512 + u];
     const int i = threadIdx.x & 63;
+    // the cloud's first compact row = the number of distinct points of the clouds before it: every wave adds those
+    // counts up itself (a 64-lane sum) instead of waiting for a one-workgroup scan launch; the wave of slot 0 publishes
+    // the offset for the kernels that follow, the last cloud's also the total (the GEMMs' device-side row count)
+    int pre = 0;
+    for (int q = i; q < b; q += 64) pre += c.cnt[q];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o, 64);
+    if (u == 0 && i == 0) {
+        c.off[b] = pre;
+        if (b == B - 1) c.total[0] = pre + c.cnt[b];
+    }
+    const long t = pre + u;
+    const long src = (long)b * Np + c.pt[(long)b * 512 + u];
     if (h1) {
         reinterpret_cast<float4*>(c3 + t * 256)[i] = reinterpret_cast<const float4*>(h3 + src * 256)[i];
         if (i < 16) reinterpret_cast<float4*>(c1 + t * 64)[i] = reinterpret_cast<const float4*>(h1 + src * 64)[i];
@@ -746,12 +732,11 @@ static int enc_critical_rows(int B, int Np, const float* x, const HpEncoderWeigh
     if (dedup) {
         // distinct critical points only, packed back to back; their number stays on the device (L.crit.total)
         hipLaunchKernelGGL(crit_unique_kernel, dim3(B), dim3(512), 0, stream, argidx, L.crit);
-        hipLaunchKernelGGL(crit_offsets_kernel, dim3(1), dim3(256), 0, stream, B, L.crit);
         const long R = (long)B * Np;
         const float* h1 = fwd_ws;
         const float* h2 = fwd_ws ? h1 + R * 64 : nullptr;
         const float* h3 = fwd_ws ? h2 + R * 128 : nullptr;
-        hipLaunchKernelGGL(crit_gather_kernel, dim3((unsigned)(Rc / 4)), dim3(256), 0, stream, Np, L.crit, x, h1, h2, h3, L.xc, L.hc[1],
+        hipLaunchKernelGGL(crit_gather_kernel, dim3((unsigned)(Rc / 4)), dim3(256), 0, stream, B, Np, L.crit, x, h1, h2, h3, L.xc, L.hc[1],
                            L.hc[2], L.hc[3]);
         if (!fwd_ws) {
             Op op{stream, nullptr, L.crit.total};
