@@ -41,6 +41,21 @@ typedef struct HpEncoderIO {
                    encoders of a pair can so write the halves of one (B, 2*out) latent [z | real mu] directly */
 } HpEncoderIO;
 
+/* One encoder's buffers for hp_encoder_backward_pair (the argument list of hp_encoder_backward_ld as a struct). */
+typedef struct HpEncoderBwdIO {
+    const float* x;              /* (B, Np, 3) */
+    const HpEncoderWeights* w;
+    const float* eps;            /* VAE only */
+    const int* argidx;
+    const float *g, *f, *lv;
+    const float *grad_out, *grad_mu, *grad_explv;
+    const HpEncoderGrads* gr;
+    float* ws;                   /* hp_encoder_backward_workspace_floats */
+    const float* fwd_ws;         /* the forward's workspace, or NULL */
+    int is_vae;
+    int grad_out_ld;
+} HpEncoderBwdIO;
+
 /* model/hyper_network.py:16-36 — trunk in->64->128->512->1024->2048, heads 2048->head_out[h] */
 typedef struct HpHyperWeights {
     const float* trunk_w[5];

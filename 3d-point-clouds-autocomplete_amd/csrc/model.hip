@@ -20,6 +20,7 @@
 #include "hp_gemm.h"
 #include "hp_model.h"
 #include "hp_skinny.h"
+#include "hp_enc_bwd.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -239,15 +240,7 @@ __global__ __launch_bounds__(256) void gather_critical_kernel(int Np, const int*
 // DISTINCT critical points: per cloud the channels are sorted by point (bitonic sort in LDS, 512 keys), each distinct
 // point gets a slot, the clouds' slots are packed back to back (`off`), and layers 4..1 see `total` rows — a count that
 // exists only on the device (HpGemmDesc::dyn_count).
-struct Crit {
-    int* chan;     // (B, 512) channels sorted by (point, channel)
-    int* start;    // (B, 513) start[u] = first sorted position of slot u, start[U] = 512
-    int* pt;       // (B, 512) point of slot u
-    int* slot;     // (B, 512) slot of channel c
-    int* cnt;      // (B)      U = number of distinct critical points
-    int* off;      // (B)      first compact row of the cloud
-    int* total;    // (1)      sum of cnt
-};
+typedef HpCrit Crit;   // hp_enc_bwd.h
 
 __global__ __launch_bounds__(512) void crit_unique_kernel(const int* __restrict__ arg, Crit c) {
     __shared__ int key[512];
@@ -438,7 +431,7 @@ __global__ __launch_bounds__(256) void vae_head_bwd_kernel(long n, const float* 
 long enc_fwd_ws(long B, long Np) { return B * Np * (64 + 128 + 256 + 512 + 512); }
 long enc_bwd_ws(long B, long out) {
     const long Rc = B * 512;
-    return Rc * 4 + Rc * (64 + 128 + 256 + 512) * 2 + B * (2 * out + 4 * 512) + kSplitWs + 64 + (B * (4 * 512 + 4) + 16);
+    return Rc * 4 + Rc * (64 + 128 + 256 + 512) * 2 + B * (2 * out + 4 * 512) + kSplitWs + 64 + (B * (5 * 512 + 4) + 16);
 }
 
 
@@ -521,52 +514,70 @@ int enc_tail_forward_skinny(int B, int out_size, int n, const EncTail* t, hipStr
 }
 
 // the autograd of that tail: dmu (and dlv) -> d mu_w/b, d std_w/b, dfc = (dmu mu_w + dlv std_w) * (f > 0), d fc_w/b,
-// dg = dfc fc_w.  Three launches instead of 7-8.  slabs: 8*64*512 floats.
-int enc_tail_backward_skinny(int B, int out_size, const float* g, const float* f, const HpEncoderWeights* w, const float* dmu,
-                             int dmu_ld, const float* dlv, const HpEncoderGrads* gr, float* dfc, float* dg, float* slabs,
-                             hipStream_t stream) {
+// dg = dfc fc_w.  Three launches instead of 7-8, shared by the n encoders (1, or the 2 of a pair: their ops sit in the same
+// phases; per encoder the tasks are those of a single-encoder program).  slabs[e]: 8*64*512 floats.
+struct EncTailBwd {
+    const float *g, *f;
+    const HpEncoderWeights* w;
+    const float* dmu;
+    int dmu_ld;
+    const float* dlv;   // NULL: plain encoder
+    const HpEncoderGrads* gr;
+    float *dfc, *dg, *slabs;
+};
+int enc_tail_backward_skinny(int B, int out_size, int n, const EncTailBwd* t, hipStream_t stream) {
     if (B > 64 || out_size % 32) return -2;
     HpSkProgram pr{};
-    const int nh = dlv ? 2 : 1;
-    const int S = sk_ranges(out_size, 512 / 32, 4 / nh);      // the two heads' ranges land in ONE slab set (<= 4 slabs)
-    for (int hd = 0; hd < nh; ++hd) {
-        HpSkOp& op = pr.op[pr.nops++];
-        op.type = HP_SK_X; op.phase = 0;
-        op.a.p = hd ? dlv : dmu; op.a.S = 1; op.a.ld = hd ? out_size : dmu_ld;
-        op.w = hd ? w->std_w : w->mu_w; op.w_ld = 512;
-        op.M = B; op.N = out_size; op.K = 512; op.CL = out_size / S;
-        op.out = slabs + (long)hd * S * 64 * 512; op.out_slab = 64L * 512; op.out_ld = 512;
-    }
-    if (nh * S == 1) return -2;                                // (a single range would apply no mask: not built)
-    for (int hd = 0; hd < nh; ++hd) {
-        HpSkOp& op = pr.op[pr.nops++];
-        op.type = HP_SK_W; op.phase = 0;
-        op.a.p = hd ? dlv : dmu; op.a.S = 1; op.a.ld = hd ? out_size : dmu_ld;
-        op.w = f; op.w_ld = 512;
-        op.out = hd ? gr->std_w : gr->mu_w; op.out_ld = 512; op.rsum = hd ? gr->std_b : gr->mu_b;
-        op.M = B; op.N = out_size; op.K = 512;
-    }
-    float* s2 = slabs + (long)nh * S * 64 * 512;
     const int S2 = sk_ranges(512, 512 / 32, 4);
     if (S2 == 1) return -2;
-    HpSkOp& xf = pr.op[pr.nops++];
-    xf.type = HP_SK_X; xf.phase = 1;
-    xf.a.p = slabs; xf.a.slab = 64L * 512; xf.a.S = nh * S; xf.a.ld = 512; xf.a.mask = f; xf.a.ldm = 512;
-    xf.a.mat = dfc; xf.a.ldmat = 512;
-    xf.w = w->fc_w; xf.w_ld = 512;
-    xf.M = B; xf.N = 512; xf.K = 512; xf.CL = 512 / S2;
-    xf.out = s2; xf.out_slab = 64L * 512; xf.out_ld = 512;
-    HpSkOp& fin = pr.op[pr.nops++];
-    fin.type = HP_SK_FIN; fin.phase = 2;
-    fin.a.p = s2; fin.a.slab = 64L * 512; fin.a.S = S2; fin.a.ld = 512;
-    fin.out = dg; fin.out_ld = 512;
-    fin.M = B; fin.N = 512; fin.K = 1;
-    HpSkOp& wf = pr.op[pr.nops++];
-    wf.type = HP_SK_W; wf.phase = 2;
-    wf.a.p = dfc; wf.a.S = 1; wf.a.ld = 512;
-    wf.w = g; wf.w_ld = 512;
-    wf.out = gr->fc_w; wf.out_ld = 512; wf.rsum = gr->fc_b;
-    wf.M = B; wf.N = 512; wf.K = 512;
+    int S[2], nh[2];
+    for (int e = 0; e < n; ++e) {
+        nh[e] = t[e].dlv ? 2 : 1;
+        S[e] = sk_ranges(out_size, 512 / 32, 4 / nh[e]);      // the two heads' ranges land in ONE slab set (<= 4 slabs)
+        if (nh[e] * S[e] == 1) return -2;                      // (a single range would apply no mask: not built)
+    }
+    for (int e = 0; e < n; ++e) {
+        for (int hd = 0; hd < nh[e]; ++hd) {
+            HpSkOp& op = pr.op[pr.nops++];
+            op.type = HP_SK_X; op.phase = 0;
+            op.a.p = hd ? t[e].dlv : t[e].dmu; op.a.S = 1; op.a.ld = hd ? out_size : t[e].dmu_ld;
+            op.w = hd ? t[e].w->std_w : t[e].w->mu_w; op.w_ld = 512;
+            op.M = B; op.N = out_size; op.K = 512; op.CL = out_size / S[e];
+            op.out = t[e].slabs + (long)hd * S[e] * 64 * 512; op.out_slab = 64L * 512; op.out_ld = 512;
+        }
+        for (int hd = 0; hd < nh[e]; ++hd) {
+            HpSkOp& op = pr.op[pr.nops++];
+            op.type = HP_SK_W; op.phase = 0;
+            op.a.p = hd ? t[e].dlv : t[e].dmu; op.a.S = 1; op.a.ld = hd ? out_size : t[e].dmu_ld;
+            op.w = t[e].f; op.w_ld = 512;
+            op.out = hd ? t[e].gr->std_w : t[e].gr->mu_w; op.out_ld = 512; op.rsum = hd ? t[e].gr->std_b : t[e].gr->mu_b;
+            op.M = B; op.N = out_size; op.K = 512;
+        }
+    }
+    for (int e = 0; e < n; ++e) {
+        float* s2 = t[e].slabs + (long)nh[e] * S[e] * 64 * 512;
+        HpSkOp& xf = pr.op[pr.nops++];
+        xf.type = HP_SK_X; xf.phase = 1;
+        xf.a.p = t[e].slabs; xf.a.slab = 64L * 512; xf.a.S = nh[e] * S[e]; xf.a.ld = 512; xf.a.mask = t[e].f; xf.a.ldm = 512;
+        xf.a.mat = t[e].dfc; xf.a.ldmat = 512;
+        xf.w = t[e].w->fc_w; xf.w_ld = 512;
+        xf.M = B; xf.N = 512; xf.K = 512; xf.CL = 512 / S2;
+        xf.out = s2; xf.out_slab = 64L * 512; xf.out_ld = 512;
+    }
+    for (int e = 0; e < n; ++e) {
+        float* s2 = t[e].slabs + (long)nh[e] * S[e] * 64 * 512;
+        HpSkOp& fin = pr.op[pr.nops++];
+        fin.type = HP_SK_FIN; fin.phase = 2;
+        fin.a.p = s2; fin.a.slab = 64L * 512; fin.a.S = S2; fin.a.ld = 512;
+        fin.out = t[e].dg; fin.out_ld = 512;
+        fin.M = B; fin.N = 512; fin.K = 1;
+        HpSkOp& wf = pr.op[pr.nops++];
+        wf.type = HP_SK_W; wf.phase = 2;
+        wf.a.p = t[e].dfc; wf.a.S = 1; wf.a.ld = 512;
+        wf.w = t[e].g; wf.w_ld = 512;
+        wf.out = t[e].gr->fc_w; wf.out_ld = 512; wf.rsum = t[e].gr->fc_b;
+        wf.M = B; wf.N = 512; wf.K = 512;
+    }
     return hp_skinny_run(&pr, stream);
 }
 }  // namespace
@@ -709,12 +720,13 @@ EncBwdWs enc_bwd_layout(float* ws, long B, long out_size) {
     L.dfc = take(B * 512);
     L.dg = take(B * 512);
     L.split = take(kSplitWs);
-    int* ip = reinterpret_cast<int*>(take(B * (4 * 512 + 4) + 16));
+    int* ip = reinterpret_cast<int*>(take(B * (5 * 512 + 4) + 16));
     L.crit.chan = ip;
     L.crit.start = L.crit.chan + B * 512;
     L.crit.pt = L.crit.start + B * 513;
     L.crit.slot = L.crit.pt + B * 512;
-    L.crit.cnt = L.crit.slot + B * 512;
+    L.crit.eslot = L.crit.slot + B * 512;
+    L.crit.cnt = L.crit.eslot + B * 512;
     L.crit.off = L.crit.cnt + B;
     L.crit.total = L.crit.off + B;
     return L;
@@ -770,82 +782,82 @@ static int enc_critical_rows(int B, int Np, const float* x, const HpEncoderWeigh
     HP_RETURN_LAST_ERROR();
 }
 
-// Gradients of every encoder parameter.  grad_out: d/d z (VAE) or d/d mu (plain); grad_mu / grad_explv:
-// direct gradients on the VAE's mu / exp(logvar) outputs (KLD term), may be NULL.  fwd_ws: the workspace
-// hp_encoder_forward ran in, untouched since (NULL: recompute the critical rows' activations instead).
+// Gradients of every encoder parameter.  grad_out: d/d z (VAE) or d/d mu (plain), a column block of a matrix with row stride
+// grad_out_ld >= out_size (the paired forward's latent [z | real mu] hands each encoder its half of d latent without a
+// copy); grad_mu / grad_explv: direct gradients on the VAE's mu / exp(logvar) outputs (KLD term), may be NULL.  fwd_ws: the
+// workspace hp_encoder_forward ran in, untouched since (NULL: recompute the critical rows' activations instead).
 // dedup != 0: channels that peak at the same point share one row below the max-pool (their gradients add): layers 4..1
 // run on the DISTINCT critical points (~1/3 of B*512), a count that stays on the device.
-HP_API int hp_encoder_backward_ld(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size, int is_vae,
-                                  const float* eps, const int* argidx, const float* g, const float* f, const float* lv,
-                                  const float* grad_out, int grad_out_ld, const float* grad_mu, const float* grad_explv,
-                                  const HpEncoderGrads* gr, float* ws, const float* fwd_ws, int dedup, hipStream_t stream);
-HP_API int hp_encoder_backward(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size, int is_vae,
-                               const float* eps, const int* argidx, const float* g, const float* f, const float* lv,
-                               const float* grad_out, const float* grad_mu, const float* grad_explv,
-                               const HpEncoderGrads* gr, float* ws, const float* fwd_ws, int dedup, hipStream_t stream) {
-    return hp_encoder_backward_ld(B, Np, x, w, out_size, is_vae, eps, argidx, g, f, lv, grad_out, out_size, grad_mu, grad_explv, gr, ws,
-                                  fwd_ws, dedup, stream);
+namespace {
+int& enc_bwd_fused_flag() {
+    static int on = env_int("HP_ENC_BWD_FUSED", 1) != 0;
+    return on;
 }
-// ... with grad_out a column block of a wider matrix (row stride grad_out_ld >= out_size: the paired forward's latent
-// [z | real mu] hands each encoder its half of d latent without a copy)
-HP_API int hp_encoder_backward_ld(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size, int is_vae,
-                                  const float* eps, const int* argidx, const float* g, const float* f, const float* lv,
-                                  const float* grad_out, int grad_out_ld, const float* grad_mu, const float* grad_explv,
-                                  const HpEncoderGrads* gr, float* ws, const float* fwd_ws, int dedup, hipStream_t stream) {
-    HP_CHECK_ARG(B > 0 && Np > 0 && out_size > 0 && x && w && argidx && g && f && gr && ws && grad_out_ld >= out_size);
-    const int gld = grad_out_ld;
-    HP_CHECK_ARG(grad_out || grad_mu || grad_explv);
-    HP_CHECK_ARG(!is_vae || (eps && lv));
+bool enc_bwd_fused_enabled() { return enc_bwd_fused_flag() != 0; }
+
+// the fc/mu/std tail's backward as tiled GEMM launches (B > 64, or the skinny layer programs switched off)
+int enc_tail_backward_gemm(int B, int out_size, const HpEncoderBwdIO& e, const float* dmu_p, int dmu_ld, const EncBwdWs& L,
+                           hipStream_t stream) {
+    Op op{stream, L.split};
+    const HpEncoderWeights* w = e.w;
+    const HpEncoderGrads* gr = e.gr;
+    if (e.is_vae) {
+        TRY(op.lin_dw(L.dlv, 0, out_size, e.f, 0, 512, gr->std_w, 0, B, out_size, 512, 1, gr->std_b));
+        TRY(op.lin_dx(L.dlv, 0, out_size, w->std_w, 0, L.tmp, 0, 512, B, out_size, 512, 1, nullptr, 0, 0, nullptr, 0));
+    }
+    TRY(op.lin_dw(dmu_p, 0, dmu_ld, e.f, 0, 512, gr->mu_w, 0, B, out_size, 512, 1, gr->mu_b));
+    TRY(op.lin_dx(dmu_p, 0, dmu_ld, w->mu_w, 0, L.dfc, 0, 512, B, out_size, 512, 1, e.f, 0, 512, e.is_vae ? L.tmp : nullptr, 512));
+    TRY(op.lin_dw(L.dfc, 0, 512, e.g, 0, 512, gr->fc_w, 0, B, 512, 512, 1, gr->fc_b));
+    TRY(op.lin_dx(L.dfc, 0, 512, w->fc_w, 0, L.dg, 0, 512, B, 512, 512, 1, nullptr, 0, 0, nullptr, 0));
+    return 0;
+}
+
+// Round-2 launch sequence (one encoder): sort, gather / recompute, delta4, dW5, then a dX GEMM, a dW GEMM and a split-K
+// reduce per layer.  Still serves dedup == 0 and the recompute path (fwd_ws == NULL).
+int encoder_backward_layered(int B, int Np, int out_size, const HpEncoderBwdIO& e, int dedup, hipStream_t stream) {
+    const HpEncoderWeights* w = e.w;
+    const HpEncoderGrads* gr = e.gr;
+    const int is_vae = e.is_vae, gld = e.grad_out_ld;
     const long Rc = (long)B * 512;
-    EncBwdWs L = enc_bwd_layout(ws, B, out_size);
+    EncBwdWs L = enc_bwd_layout(e.ws, B, out_size);
     float* xc = L.xc;
     float** hc = L.hc;
     float** dl = L.dl;
-    float *dmu = L.dmu, *dlv = L.dlv, *tmp = L.tmp, *dfc = L.dfc, *dg = L.dg;
-    Op op{stream, L.split};
-    HP_CHECK_ARG(!dedup || (long)Np * 512 < (1L << 31));
-    TRY(enc_critical_rows(B, Np, x, w, out_size, argidx, fwd_ws, ws, dedup, stream));
+    float *dmu = L.dmu, *dlv = L.dlv, *dfc = L.dfc, *dg = L.dg;
+    TRY(enc_critical_rows(B, Np, e.x, w, out_size, e.argidx, e.fwd_ws, e.ws, dedup, stream));
 
     // ---- heads (model/encoder.py:46-53)
     const float* dmu_p;
     if (is_vae) {
         const long n = (long)B * out_size;
-        hipLaunchKernelGGL(vae_head_bwd_kernel, dim3((int)cdiv(n, 256)), dim3(256), 0, stream, n, eps, lv, grad_out, out_size,
-                           gld, grad_mu, grad_explv, dmu, dlv);
+        hipLaunchKernelGGL(vae_head_bwd_kernel, dim3((int)cdiv(n, 256)), dim3(256), 0, stream, n, e.eps, e.lv, e.grad_out, out_size,
+                           gld, e.grad_mu, e.grad_explv, dmu, dlv);
         dmu_p = dmu;
     } else {
-        dmu_p = grad_out;
+        dmu_p = e.grad_out;
     }
     const int dmu_ld = is_vae ? out_size : gld;
     int sk = -2;
-    if (hp_skinny_enabled() && B <= 64 && dmu_p && dmu_ld % 4 == 0)
-        sk = enc_tail_backward_skinny(B, out_size, g, f, w, dmu_p, dmu_ld, is_vae ? dlv : nullptr, gr, dfc, dg, L.split, stream);
-    if (sk != -2) {
-        TRY(sk);
-    } else {
-        if (is_vae) {
-            TRY(op.lin_dw(dlv, 0, out_size, f, 0, 512, gr->std_w, 0, B, out_size, 512, 1, gr->std_b));
-            TRY(op.lin_dx(dlv, 0, out_size, w->std_w, 0, tmp, 0, 512, B, out_size, 512, 1, nullptr, 0, 0, nullptr, 0));
-        }
-        TRY(op.lin_dw(dmu_p, 0, dmu_ld, f, 0, 512, gr->mu_w, 0, B, out_size, 512, 1, gr->mu_b));
-        TRY(op.lin_dx(dmu_p, 0, dmu_ld, w->mu_w, 0, dfc, 0, 512, B, out_size, 512, 1, f, 0, 512, is_vae ? tmp : nullptr, 512));
-        TRY(op.lin_dw(dfc, 0, 512, g, 0, 512, gr->fc_w, 0, B, 512, 512, 1, gr->fc_b));
-        TRY(op.lin_dx(dfc, 0, 512, w->fc_w, 0, dg, 0, 512, B, 512, 512, 1, nullptr, 0, 0, nullptr, 0));
+    if (hp_skinny_enabled() && B <= 64 && dmu_p && dmu_ld % 4 == 0) {
+        const EncTailBwd t{e.g, e.f, w, dmu_p, dmu_ld, is_vae ? dlv : nullptr, gr, dfc, dg, L.split};
+        sk = enc_tail_backward_skinny(B, out_size, 1, &t, stream);
     }
+    if (sk != -2) TRY(sk);
+    else TRY(enc_tail_backward_gemm(B, out_size, e, dmu_p, dmu_ld, L, stream));
 
     // ---- conv stack on the critical rows (B*512 of them, or the distinct ones)
-    const float* h4_full = fwd_ws ? fwd_ws + (long)B * Np * (64 + 128 + 256) : nullptr;
+    const float* h4_full = e.fwd_ws ? e.fwd_ws + (long)B * Np * (64 + 128 + 256) : nullptr;
     Op opc{stream, L.split, dedup ? L.crit.total : nullptr};
     if (dedup) {
         hipLaunchKernelGGL(enc_l5_bwd_kernel, dim3(512), dim3(512), 0, stream, B, 512, 512, dg, w->conv_w[4],
-                           h4_full ? h4_full : hc[4], h4_full ? argidx : (const int*)nullptr, Np,
+                           h4_full ? h4_full : hc[4], h4_full ? e.argidx : (const int*)nullptr, Np,
                            h4_full ? (const int*)nullptr : L.crit.slot, h4_full ? (const int*)nullptr : L.crit.off,
                            gr->conv_w[4], (float*)nullptr, gr->conv_b[4]);
         hipLaunchKernelGGL(crit_l5_dx_kernel, dim3((unsigned)Rc), dim3(128), 0, stream, Np, L.crit, dg, w->conv_w[4],
                            h4_full ? h4_full : hc[4], h4_full ? 1 : 0, dl[4]);
     } else {
         hipLaunchKernelGGL(enc_l5_bwd_kernel, dim3(512), dim3(512), 0, stream, B, 512, 512, dg, w->conv_w[4],
-                           h4_full ? h4_full : hc[4], h4_full ? argidx : (const int*)nullptr, Np, (const int*)nullptr,
+                           h4_full ? h4_full : hc[4], h4_full ? e.argidx : (const int*)nullptr, Np, (const int*)nullptr,
                            (const int*)nullptr, gr->conv_w[4], dl[4], gr->conv_b[4]);
     }
     for (int l = 4; l >= 1; --l) {
@@ -857,6 +869,101 @@ HP_API int hp_encoder_backward_ld(int B, int Np, const float* x, const HpEncoder
                            hc[l - 1], 0, kEnc[l - 1], nullptr, 0));
     }
     HP_RETURN_LAST_ERROR();
+}
+
+inline bool a16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+// Round 3: the conv stacks of the n encoders in prep + chain + dW + reduce launches (enc_bwd.hip), their tails in three
+// shared skinny launches: 7 launches for a HyperPocket step's two encoders (round 2: ~34 on two streams).
+int encoder_backward_fused(int B, int Np, int out_size, int n, const HpEncoderBwdIO* io, hipStream_t stream) {
+    HpEncBwdArgs a{};
+    a.n = n; a.B = B; a.Np = Np; a.out = out_size;
+    a.S = std::max(1, std::min(B, std::min(env_int("HP_EB_SPLITS", 23), HP_EB_MAX_SPLITS)));   // S <= B: the h4 slot holds the partials
+    EncBwdWs L[2];
+    EncTailBwd t[2];
+    bool skinny_ok = hp_skinny_enabled() && B <= 64;
+    for (int z = 0; z < n; ++z) {
+        const HpEncoderBwdIO& e = io[z];
+        L[z] = enc_bwd_layout(e.ws, B, out_size);
+        HpEncBwdSide& s = a.e[z];
+        s.x = e.x; s.argidx = e.argidx; s.dg = L[z].dg;
+        const long R = (long)B * Np;
+        s.h[0] = nullptr;
+        s.h[1] = e.fwd_ws;
+        for (int l = 2; l <= 4; ++l) s.h[l] = s.h[l - 1] + R * kEnc[l - 1];
+        for (int l = 0; l < 5; ++l) {
+            s.W[l] = e.w->conv_w[l];
+            s.gW[l] = e.gr->conv_w[l];
+            s.gb[l] = e.gr->conv_b[l];
+        }
+        s.eps = e.eps; s.lv = e.lv; s.gout = e.grad_out; s.gmu = e.grad_mu; s.gexplv = e.grad_explv;
+        s.dmu = L[z].dmu; s.dlv = L[z].dlv; s.is_vae = e.is_vae; s.gout_ld = e.grad_out_ld;
+        s.crit = L[z].crit;
+        for (int l = 1; l <= 4; ++l) s.d[l] = L[z].dl[l];
+        s.hc[0] = L[z].xc;
+        for (int l = 1; l <= 3; ++l) s.hc[l] = L[z].hc[l];
+        s.part = L[z].hc[4];                      // (B*512 x 512 floats; the fused path never gathers h4)
+        const float* dmu_p = e.is_vae ? L[z].dmu : e.grad_out;
+        const int dmu_ld = e.is_vae ? out_size : e.grad_out_ld;
+        t[z] = EncTailBwd{e.g, e.f, e.w, dmu_p, dmu_ld, e.is_vae ? L[z].dlv : nullptr, e.gr, L[z].dfc, L[z].dg, L[z].split};
+        skinny_ok = skinny_ok && dmu_p && dmu_ld % 4 == 0;
+    }
+    TRY(hp_enc_bwd_prep(&a, stream));
+    int sk = skinny_ok ? enc_tail_backward_skinny(B, out_size, n, t, stream) : -2;
+    if (sk != -2) TRY(sk);
+    else
+        for (int z = 0; z < n; ++z) TRY(enc_tail_backward_gemm(B, out_size, io[z], t[z].dmu, t[z].dmu_ld, L[z], stream));
+    return hp_enc_bwd_conv(&a, stream);
+}
+
+bool enc_bwd_io_ok(const HpEncoderBwdIO& e, int out_size) {
+    return e.x && e.w && e.argidx && e.g && e.f && e.gr && e.ws && e.grad_out_ld >= out_size &&
+           (e.grad_out || e.grad_mu || e.grad_explv) && (!e.is_vae || (e.eps && e.lv));
+}
+bool enc_bwd_can_fuse(const HpEncoderBwdIO& e) {
+    if (!e.fwd_ws || !a16(e.fwd_ws) || !a16(e.ws)) return false;
+    for (int l = 0; l < 5; ++l)
+        if (!a16(e.w->conv_w[l]) || !a16(e.gr->conv_w[l]) || !a16(e.gr->conv_b[l])) return false;
+    return true;
+}
+
+int encoder_backward_impl(int B, int Np, int out_size, int n, const HpEncoderBwdIO* io, int dedup, hipStream_t stream) {
+    HP_CHECK_ARG(B > 0 && Np > 0 && out_size > 0 && io && n >= 1 && n <= 2);
+    for (int z = 0; z < n; ++z) HP_CHECK_ARG(enc_bwd_io_ok(io[z], out_size));
+    HP_CHECK_ARG(!dedup || (long)Np * 512 < (1L << 31));
+    bool fuse = dedup && enc_bwd_fused_enabled() && out_size <= 512 && B <= hp_enc_bwd_max_clouds();
+    for (int z = 0; z < n; ++z) fuse = fuse && enc_bwd_can_fuse(io[z]);
+    if (fuse) return encoder_backward_fused(B, Np, out_size, n, io, stream);
+    for (int z = 0; z < n; ++z) TRY(encoder_backward_layered(B, Np, out_size, io[z], dedup, stream));
+    return 0;
+}
+}  // namespace
+
+HP_API int hp_encoder_backward_ld(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size, int is_vae,
+                                  const float* eps, const int* argidx, const float* g, const float* f, const float* lv,
+                                  const float* grad_out, int grad_out_ld, const float* grad_mu, const float* grad_explv,
+                                  const HpEncoderGrads* gr, float* ws, const float* fwd_ws, int dedup, hipStream_t stream) {
+    const HpEncoderBwdIO io{x, w, eps, argidx, g, f, lv, grad_out, grad_mu, grad_explv, gr, ws, fwd_ws, is_vae, grad_out_ld};
+    return encoder_backward_impl(B, Np, out_size, 1, &io, dedup, stream);
+}
+HP_API int hp_encoder_backward(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size, int is_vae,
+                               const float* eps, const int* argidx, const float* g, const float* f, const float* lv,
+                               const float* grad_out, const float* grad_mu, const float* grad_explv,
+                               const HpEncoderGrads* gr, float* ws, const float* fwd_ws, int dedup, hipStream_t stream) {
+    return hp_encoder_backward_ld(B, Np, x, w, out_size, is_vae, eps, argidx, g, f, lv, grad_out, out_size, grad_mu, grad_explv, gr, ws,
+                                  fwd_ws, dedup, stream);
+}
+// Switches the fused conv-stack backward (enc_bwd.hip) on/off for the parity tests; returns the previous setting.
+HP_API int hp_encoder_backward_set_fused(int on) {
+    const int prev = enc_bwd_fused_flag();
+    enc_bwd_fused_flag() = on != 0;
+    return prev;
+}
+// Both encoders of a HyperPocket step in one call (io[0], io[1]: hp_encoder_backward_ld's arguments as structs; same B, Np,
+// out_size), on ONE stream: the two conv stacks share the prep / chain / dW / reduce launches, the two tails three skinny
+// launches.  Results are those of two hp_encoder_backward_ld calls, bit for bit.
+HP_API int hp_encoder_backward_pair(int B, int Np, int out_size, const HpEncoderBwdIO* io, int dedup, hipStream_t stream) {
+    return encoder_backward_impl(B, Np, out_size, 2, io, dedup, stream);
 }
 
 // =================================================================================================

@@ -34,7 +34,7 @@ constexpr int kThreads = 256;
 constexpr int kCLMax = 128;                       // contraction chunk staged per pass
 constexpr int kLdsFloats = 96 * (kCLMax + 4);     // staged A (64 rows) + W (32 rows) blocks; the cross-wave reduce aliases them
 
-constexpr int kPhaseOps = 4;   // ops per launch (a phase with more is split: its ops are independent)
+constexpr int kPhaseOps = 8;   // ops per launch (a phase with more is split: its ops are independent)
 struct Prog {                  // the kernel argument: only the launch's own ops (the CPU copies it per launch)
     int nops;
     HpSkOp op[kPhaseOps];

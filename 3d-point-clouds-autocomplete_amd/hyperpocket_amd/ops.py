@@ -25,6 +25,13 @@ class _EncoderIO(ctypes.Structure):  # HpEncoderIO (one encoder's buffers for hp
                 ("ws", c_void_p), ("is_vae", c_int), ("out_ld", c_int)]
 
 
+class _EncoderBwdIO(ctypes.Structure):  # HpEncoderBwdIO (one encoder's buffers for hp_encoder_backward_pair)
+    _fields_ = [("x", c_void_p), ("w", ctypes.POINTER(_EncoderPtrs)), ("eps", c_void_p), ("argidx", c_void_p),
+                ("g", c_void_p), ("f", c_void_p), ("lv", c_void_p), ("grad_out", c_void_p), ("grad_mu", c_void_p),
+                ("grad_explv", c_void_p), ("gr", ctypes.POINTER(_EncoderPtrs)), ("ws", c_void_p), ("fwd_ws", c_void_p),
+                ("is_vae", c_int), ("grad_out_ld", c_int)]
+
+
 class _HyperWeights(ctypes.Structure):  # HpHyperWeights
     _fields_ = [("trunk_w", c_void_p * 5), ("trunk_b", c_void_p * 5), ("n_heads", c_int),
                 ("head_out", c_int * HP_MAX_HEADS), ("head_w", c_void_p * HP_MAX_HEADS),
@@ -85,6 +92,9 @@ KEEP_ENCODER_ACTIVATIONS = True
 # Channels whose max-pool peaks at the same point share every activation below it: the encoder backward runs its
 # layers 4..1 on the distinct critical points (~170 of 512 per cloud).  False: one row per (cloud, channel).
 DEDUP_CRITICAL_ROWS = True
+# The two encoders of a HyperPocket step share the launches of their backward (hp_encoder_backward_pair, one stream).
+# False: two hp_encoder_backward_ld calls on two streams (round 2's form).
+PAIRED_ENCODER_BACKWARD = True
 
 
 def _encoder_struct(params, cls=_EncoderPtrs):
@@ -153,8 +163,7 @@ class EncoderFunction(Function):
 
 class EncoderPairFunction(Function):
     """The two encoders of a HyperPocket training step (model/full_model.py:106-112) as ONE node: the conv stacks of both run
-    as batched launches (hp_encoder_forward_pair); the backward runs the two independent hp_encoder_backward chains on two
-    streams.  Arguments: x_vae (missing), eps, x_plain (existing), out_size, side stream, then the VAE encoder's 16
+    as batched launches (hp_encoder_forward_pair), and so do their backward's (hp_encoder_backward_pair).  Arguments: x_vae (missing), eps, x_plain (existing), out_size, side stream, then the VAE encoder's 16
     parameters and the plain encoder's 14.  Returns (latent, mu, exp(logvar)) with latent = [z | real_mu] (B, 2*out): the two
     encoders write its halves directly (no torch.cat) and the backward reads the halves of d latent in place."""
 
@@ -223,7 +232,25 @@ class EncoderPairFunction(Function):
                  f, lv, ctypes.c_void_p(gout.data_ptr()), 2 * ctx.out_size, gm, ge, ctypes.byref(gr), ws, fwd_ws,
                  int(DEDUP_CRITICAL_ROWS), current_stream(dev))
 
-        # the two chains are independent (~17 small launches each): the VAE encoder's goes to the side stream
+        if PAIRED_ENCODER_BACKWARD:
+            # one call, one stream: the conv stacks of both encoders in four shared launches, the tails in three
+            io = (_EncoderBwdIO * 2)()
+            keep = []
+            for e, (x, ps, outs, vae, argidx, g, f, lv, gout, gm, ge, fwd_ws) in enumerate((
+                    (x0, p0, out0, True, arg0, g0, f0, lv0, gz, gmu, gexplv, ctx.fwd_ws[0]),
+                    (x1, p1, out1, False, arg1, g1, f1, None, greal, None, None, ctx.fwd_ws[1]))):
+                ws = torch.empty((nws,), dtype=torch.float32, device=dev)
+                w, gr = _encoder_struct(ps), _encoder_struct(outs)
+                keep.append((ws, w, gr))
+                io[e].x, io[e].w, io[e].eps, io[e].argidx = x.data_ptr(), ctypes.pointer(w), _dp(eps if vae else None), argidx.data_ptr()
+                io[e].g, io[e].f, io[e].lv = g.data_ptr(), f.data_ptr(), _dp(lv)
+                io[e].grad_out, io[e].grad_mu, io[e].grad_explv = gout.data_ptr(), _dp(gm), _dp(ge)
+                io[e].gr, io[e].ws, io[e].fwd_ws = ctypes.pointer(gr), ws.data_ptr(), _dp(fwd_ws)
+                io[e].is_vae, io[e].grad_out_ld = int(vae), 2 * ctx.out_size
+            call("hp_encoder_backward_pair", B, Np, ctx.out_size, io, int(DEDUP_CRITICAL_ROWS), current_stream(dev))
+            ctx.fwd_ws = None
+            return (None, None, None, None, None, *out0, *out1)
+        # the two chains are independent: the VAE encoder's goes to the side stream
         if side is not cur:
             side.wait_stream(cur)
         with torch.cuda.stream(side):

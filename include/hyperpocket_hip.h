@@ -224,6 +224,29 @@ int hp_encoder_backward_ld(int B, int Np, const float* x, const HpEncoderWeights
                            const float* eps, const int* argidx, const float* g, const float* f, const float* lv,
                            const float* grad_out, int grad_out_ld, const float* grad_mu, const float* grad_explv,
                            const HpEncoderGrads* grads, float* ws, const float* fwd_ws, int dedup, hpStream_t stream);
+/* Both encoders of a HyperPocket step in one call, on one stream (round 3): with the forward's workspaces at hand and
+ * dedup != 0 the two conv stacks share four launches (sort, a row-block chain delta4 -> delta1 on the matrix cores, one
+ * grouped launch for every weight/bias gradient, an ordered reduce — csrc/enc_bwd.hip) and the two fc/mu/std tails three.
+ * Results are those of two hp_encoder_backward_ld calls, bit for bit.  Autograd of model/encoder.py:14-53 for
+ * model/full_model.py:106-112's two encoders. */
+typedef struct HpEncoderBwdIO {
+    const float* x;              /* (B, Np, 3) */
+    const HpEncoderWeights* w;
+    const float* eps;            /* VAE only */
+    const int* argidx;
+    const float *g, *f, *lv;
+    const float *grad_out, *grad_mu, *grad_explv;
+    const HpEncoderGrads* gr;
+    float* ws;                   /* hp_encoder_backward_workspace_floats */
+    const float* fwd_ws;         /* the forward's workspace, or NULL */
+    int is_vae;
+    int grad_out_ld;
+} HpEncoderBwdIO;
+int hp_encoder_backward_pair(int B, int Np, int out_size, const HpEncoderBwdIO* io /* [2] */, int dedup, hpStream_t stream);
+/* Parity-test switch: 0 sends every encoder backward through round 2's layered launch sequence (sort, gather, a dX GEMM,
+ * a dW GEMM and a split-K reduce per layer), 1 (default) through the fused kernels when fwd_ws != NULL and dedup != 0.
+ * Returns the previous setting. */
+int hp_encoder_backward_set_fused(int on);
 
 /* HyperNetwork.forward (model/hyper_network.py:41-43): latent (B,in) -> theta (B,theta_ld); t = saved trunk
  * activations (hp_hypernet_saved_floats floats) for the backward. */

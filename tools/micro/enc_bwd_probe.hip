@@ -1,0 +1,88 @@
+// Standalone timing harness for csrc/enc_bwd.hip (prep / chain / dW / reduce) on synthetic data shaped like the bench step:
+// two encoders, B = 64 clouds of Np = 1024 points, ~170 distinct critical points per cloud with a heavy-tailed multiplicity.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I3d-point-clouds-autocomplete_amd/csrc -o tools/micro/enc_bwd_probe tools/micro/enc_bwd_probe.hip
+// Timing only: parity of these kernels is tests/test_model_gpu.py's job.
+#include "../../3d-point-clouds-autocomplete_amd/csrc/enc_bwd.hip"
+#include <random>
+#include <cstring>
+
+static float* dalloc(size_t n, float scale, std::mt19937& g) {
+    float* d; hipMalloc(&d, n * 4);
+    std::vector<float> h(std::min<size_t>(n, 1 << 22));
+    std::uniform_real_distribution<float> u(-scale, scale);
+    for (auto& v : h) v = u(g);
+    for (size_t o = 0; o < n; o += h.size()) hipMemcpy(d + o, h.data(), std::min(h.size(), n - o) * 4, hipMemcpyHostToDevice);
+    return d;
+}
+int main(int argc, char** argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 64, Np = 1024, n = 2, S = argc > 2 ? atoi(argv[2]) : 16, reps = 20;
+    std::mt19937 g(1);
+    HpEncBwdArgs a{};
+    a.n = n; a.B = B; a.Np = Np; a.out = 128; a.S = std::min(S, B);
+    const int kE[6] = {3, 64, 128, 256, 512, 512};
+    for (int z = 0; z < n; ++z) {
+        HpEncBwdSide& s = a.e[z];
+        const size_t R = (size_t)B * Np, Rc = (size_t)B * 512;
+        s.x = dalloc(R * 3, 0.5f, g);
+        s.dg = dalloc(Rc, 1.f, g);
+        for (int l = 0; l < 5; ++l) {
+            s.W[l] = dalloc((size_t)kE[l + 1] * kE[l], 0.1f, g);
+            s.gW[l] = dalloc((size_t)kE[l + 1] * kE[l], 0.f, g);
+            s.gb[l] = dalloc(kE[l + 1], 0.f, g);
+        }
+        for (int l = 1; l <= 4; ++l) s.h[l] = dalloc(R * kE[l], 1.f, g);
+        for (int l = 1; l <= 4; ++l) s.d[l] = dalloc(Rc * kE[l], 0.f, g);
+        s.hc[0] = dalloc(Rc * 3, 0.f, g);
+        for (int l = 1; l <= 3; ++l) s.hc[l] = dalloc(Rc * kE[l], 0.f, g);
+        s.part = dalloc((size_t)HP_EB_MAX_SPLITS * HP_EB_PART_FLOATS, 0.f, g);
+        s.is_vae = 0;
+        // arg-max points: ~170 distinct per cloud, a few of them carrying 20-50 channels
+        std::vector<int> arg(Rc);
+        std::uniform_real_distribution<float> u(0.f, 1.f);
+        for (int b = 0; b < B; ++b) {
+            std::vector<int> pts(260);
+            for (auto& p : pts) p = (int)(u(g) * Np) % Np;
+            for (int c = 0; c < 512; ++c) {
+                const float r = u(g);
+                arg[(size_t)b * 512 + c] = pts[(int)(r * r * r * 259.99f)];
+            }
+        }
+        int* dargi; hipMalloc(&dargi, Rc * 4); hipMemcpy(dargi, arg.data(), Rc * 4, hipMemcpyHostToDevice);
+        s.argidx = dargi;
+        int* ip; hipMalloc(&ip, ((size_t)B * (5 * 512 + 4) + 16) * 4);
+        s.crit.chan = ip; s.crit.start = s.crit.chan + B * 512; s.crit.pt = s.crit.start + B * 513; s.crit.slot = s.crit.pt + B * 512;
+        s.crit.eslot = s.crit.slot + B * 512; s.crit.cnt = s.crit.eslot + B * 512; s.crit.off = s.crit.cnt + B; s.crit.total = s.crit.off + B;
+    }
+    hp_enc_bwd_prep(&a, 0);
+    hipDeviceSynchronize();
+    std::vector<int> cnt(B);
+    hipMemcpy(cnt.data(), a.e[0].crit.cnt, B * 4, hipMemcpyDeviceToHost);
+    long tot = 0; for (int v : cnt) tot += v;
+    printf("B %d S %d: %.1f distinct critical points per cloud\n", B, a.S, (double)tot / B);
+    hipEvent_t ev[6];
+    for (auto& e : ev) hipEventCreate(&e);
+    double acc[5] = {0};
+    const long ngat = (long)(512 + (long)B * 32) * n, nblk = (long)B * 16 * n, ndw = (long)a.S * kRangeWgs * n;
+    for (int it = -3; it < reps; ++it) {
+        hipEventRecord(ev[0]);
+        hipLaunchKernelGGL(enc_bwd_prep_kernel, dim3(B, n), dim3(512), 0, 0, a);
+        hipEventRecord(ev[1]);
+        hipLaunchKernelGGL(enc_bwd_gather_kernel, dim3((unsigned)ngat), dim3(256), 0, 0, a);
+        hipEventRecord(ev[5]);
+        hipLaunchKernelGGL(enc_bwd_chain_kernel, dim3((unsigned)nblk), dim3(kChainThreads), 0, 0, a);
+        hipEventRecord(ev[2]);
+        hipLaunchKernelGGL(enc_bwd_dw_kernel, dim3((unsigned)ndw), dim3(256), 0, 0, a);
+        hipEventRecord(ev[3]);
+        hipLaunchKernelGGL(enc_bwd_reduce_kernel, dim3((HP_EB_PART_FLOATS / 4 + 255) / 256, n), dim3(256), 0, 0, a);
+        hipEventRecord(ev[4]);
+        hipEventSynchronize(ev[4]);
+        if (it < 0) continue;
+        const int order[6] = {0, 1, 5, 2, 3, 4};
+        for (int k = 0; k < 5; ++k) { float ms; hipEventElapsedTime(&ms, ev[order[k]], ev[order[k + 1]]); acc[k] += ms * 1e3 / reps; }
+    }
+    printf("prep %.1f | gather %.1f | chain %.1f | dW %.1f | reduce %.1f | sum %.1f us  (hipEvent deltas, back to back)\n", acc[0], acc[1], acc[2], acc[3],
+           acc[4], acc[0] + acc[1] + acc[2] + acc[3] + acc[4]);
+    if (getenv("HP_EB_PROF")) hp_enc_bwd_conv(&a, 0);
+    hipDeviceSynchronize();
+    return 0;
+}
