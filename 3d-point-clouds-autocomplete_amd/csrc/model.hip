@@ -875,7 +875,17 @@ inline bool a16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) ==
 
 // Round 3: the conv stacks of the n encoders in prep + chain + dW + reduce launches (enc_bwd.hip), their tails in three
 // shared skinny launches: 7 launches for a HyperPocket step's two encoders (round 2: ~34 on two streams).
-int encoder_backward_fused(int B, int Np, int out_size, int n, const HpEncoderBwdIO* io, hipStream_t stream) {
+// `after` (may be NULL): a stream to be ordered behind the tails' launches (event record on `stream`, wait on `after`).
+int order_behind(hipStream_t stream, hipStream_t after) {
+    if (!after || after == stream) return 0;
+    static hipEvent_t ev = nullptr;      // one device per process; re-recording an event is legal, waits bind to the record they follow
+    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+    if (hipEventRecord(ev, stream) != hipSuccess) return (int)hipGetLastError();
+    if (hipStreamWaitEvent(after, ev, 0) != hipSuccess) return (int)hipGetLastError();
+    return 0;
+}
+
+int encoder_backward_fused(int B, int Np, int out_size, int n, const HpEncoderBwdIO* io, hipStream_t stream, hipStream_t after) {
     HpEncBwdArgs a{};
     a.n = n; a.B = B; a.Np = Np; a.out = out_size;
     a.S = std::max(1, std::min(B, std::min(env_int("HP_EB_SPLITS", 23), HP_EB_MAX_SPLITS)));   // S <= B: the h4 slot holds the partials
@@ -913,6 +923,7 @@ int encoder_backward_fused(int B, int Np, int out_size, int n, const HpEncoderBw
     if (sk != -2) TRY(sk);
     else
         for (int z = 0; z < n; ++z) TRY(enc_tail_backward_gemm(B, out_size, io[z], t[z].dmu, t[z].dmu_ld, L[z], stream));
+    TRY(order_behind(stream, after));
     return hp_enc_bwd_conv(&a, stream);
 }
 
@@ -927,13 +938,15 @@ bool enc_bwd_can_fuse(const HpEncoderBwdIO& e) {
     return true;
 }
 
-int encoder_backward_impl(int B, int Np, int out_size, int n, const HpEncoderBwdIO* io, int dedup, hipStream_t stream) {
+int encoder_backward_impl(int B, int Np, int out_size, int n, const HpEncoderBwdIO* io, int dedup, hipStream_t stream,
+                          hipStream_t after = nullptr) {
     HP_CHECK_ARG(B > 0 && Np > 0 && out_size > 0 && io && n >= 1 && n <= 2);
     for (int z = 0; z < n; ++z) HP_CHECK_ARG(enc_bwd_io_ok(io[z], out_size));
     HP_CHECK_ARG(!dedup || (long)Np * 512 < (1L << 31));
     bool fuse = dedup && enc_bwd_fused_enabled() && out_size <= 512 && B <= hp_enc_bwd_max_clouds();
     for (int z = 0; z < n; ++z) fuse = fuse && enc_bwd_can_fuse(io[z]);
-    if (fuse) return encoder_backward_fused(B, Np, out_size, n, io, stream);
+    if (fuse) return encoder_backward_fused(B, Np, out_size, n, io, stream, after);
+    TRY(order_behind(stream, after));      // (the layered launches are small: nothing to keep clear of)
     for (int z = 0; z < n; ++z) TRY(encoder_backward_layered(B, Np, out_size, io[z], dedup, stream));
     return 0;
 }
@@ -952,6 +965,12 @@ HP_API int hp_encoder_backward(int B, int Np, const float* x, const HpEncoderWei
                                const HpEncoderGrads* gr, float* ws, const float* fwd_ws, int dedup, hipStream_t stream) {
     return hp_encoder_backward_ld(B, Np, x, w, out_size, is_vae, eps, argidx, g, f, lv, grad_out, out_size, grad_mu, grad_explv, gr, ws,
                                   fwd_ws, dedup, stream);
+}
+// ... and a stream `after` (may be NULL) that is ordered behind the two tails' launches: work the caller enqueues on it
+// afterwards starts when the tails are done, beside the conv-stack launches (core/engine.py: the heads' dW + Adam pass).
+HP_API int hp_encoder_backward_pair_ordered(int B, int Np, int out_size, const HpEncoderBwdIO* io, int dedup, hipStream_t stream,
+                                            hipStream_t after) {
+    return encoder_backward_impl(B, Np, out_size, 2, io, dedup, stream, after);
 }
 // Switches the fused conv-stack backward (enc_bwd.hip) on/off for the parity tests; returns the previous setting.
 HP_API int hp_encoder_backward_set_fused(int on) {

@@ -101,7 +101,7 @@ class FusedHeadsAdam:
     hypernetwork backward (which still needs the OLD weights for d t5 = d theta . W) one kernel forms it tile by tile in
     registers and applies Adam to W / exp_avg / exp_avg_sq in place (hp_hypernet_heads_dw_adam): 6 x 156 MB of HBM traffic
     instead of the 8 x 156 MB of "write dW, then one Adam pass over it", and the step's last Adam pass shrinks to the
-    17 MB of everything else.  Same object protocol as HeadsShard (ops.HEADS_DW_EXCHANGE)."""
+    17 MB of everything else.  Same object protocol as HeadsShard (ops.py: the heads' exchange object)."""
 
     def __init__(self, engine, own_stream=True):
         h = engine.flat.heads
@@ -111,7 +111,10 @@ class FusedHeadsAdam:
         # dependent launches that leave HBM idle.  On a stream of its own the two overlap; `join` orders it before the next
         # reader of the heads' weights.
         self.stream = torch.cuda.Stream(device=engine.flat.flat.device) if own_stream else None
-        self._keep = None
+        self._keep = self._job = None
+        self.ran = False           # the pass of the step in flight has been launched (step() then leaves the heads to it)
+        import os
+        self.defer = os.environ.get("HP_HEADS_ADAM_DEFER", "1") != "0"
 
     accepts = HeadsShard.accepts
 
@@ -119,24 +122,51 @@ class FusedHeadsAdam:
         pass                                   # nothing to exchange
 
     def finish(self, grad_theta, t5):
-        """Called by HyperNetFunction.backward AFTER hp_hypernet_backward has been enqueued (stream order: after d t5)."""
+        """Called by HyperNetFunction.backward AFTER hp_hypernet_backward has been enqueued (stream order: after d t5).
+        With a stream of its own the pass is not launched here: it saturates HBM from every CU for ~180 us, and the
+        launches that follow on the compute stream — the encoders' fc/mu/std tails, 372-VGPR latency-built workgroups
+        that need empty SIMDs — would sit behind it for that long.  The encoder pair's backward launches it behind its
+        tails instead (`launch_ordered`, ops.EncoderPairFunction), beside the matrix-bound conv-stack launches;
+        `flush` launches it at the latest when backward is over (modes without the paired encoders)."""
+        self._job = (grad_theta, t5)
+        self.ran = False
+        if self.stream is None or not self.defer:
+            self.flush()
+
+    def pending(self):
+        return self._job is not None
+
+    def _launch(self, st):
         e = self.engine
+        grad_theta, t5 = self._job
         n = self.rows * self.cols
         dev = grad_theta.device
-        cur = torch.cuda.current_stream(dev)
-        st = self.stream if self.stream is not None else cur
-        if st is not cur:
-            st.wait_stream(cur)
-            self._keep = (grad_theta, t5)      # alive until join(): the side stream reads them
+        self._keep, self._job = (grad_theta, t5), None      # alive until join(): the side stream reads them
         with torch.cuda.stream(st):
             call("hp_hypernet_heads_dw_adam", grad_theta.size(0), self.rows, 0, grad_theta, grad_theta.size(1), t5,
                  self.flat.flat[self.lo:self.lo + n], e.exp_avg[self.lo:self.lo + n], e.exp_avg_sq[self.lo:self.lo + n],
                  float(e.lr), float(e.betas[0]), float(e.betas[1]), float(e.eps), int(e._adam_step), current_stream(dev))
+        self.ran = True
+
+    def launch_ordered(self):
+        """The caller has ordered `self.stream` behind the point of the compute stream the pass may start at."""
+        if self._job is not None:
+            self._launch(self.stream)
+
+    def flush(self):
+        if self._job is None:
+            return
+        cur = torch.cuda.current_stream(self._job[0].device)
+        st = self.stream if self.stream is not None else cur
+        if st is not cur:
+            st.wait_stream(cur)
+        self._launch(st)
 
     def join(self):
+        self.flush()
         if self.stream is not None and self._keep is not None:
             torch.cuda.current_stream(self.flat.flat.device).wait_stream(self.stream)
-            self._keep = None
+        self._keep = None
 
 
 class TrainEngine:
@@ -180,7 +210,6 @@ class TrainEngine:
         if self.shard is not None:
             # d theta / t5 were gathered under the hypernetwork's own backward launches; the heads' rows are updated
             # and on their way before the encoders' backward is even enqueued
-            ops.HEADS_DW_EXCHANGE = None
             self.shard.update()
             lo, hi = self.shard.hi, self.flat.buckets[1][1]      # heads' biases + trunk: plain all-reduce, deferred
             self.reducer.launch("small", lo, hi)
@@ -197,6 +226,12 @@ class TrainEngine:
         assert self.flat.is_intact(), "parameters were re-allocated (e.g. .to()) after TrainEngine construction"
         self.flat.clear_param_grads()
         device = gt.device
+        # who takes the heads' weight gradient of THIS step's hypernetwork node (state of this model, not of the process)
+        exch = self.shard if (self.exchange and self.shard is not None) else (self.fused if not self.exchange else None)
+        model.hyper_network._heads_exchange = exch
+        model._after_encoder_tails = self.fused if (self.fused is not None and self.fused.stream is not None) else None
+        if self.fused is not None:
+            self.fused.ran = False
         # forward() transposes its inputs in place: hand it views it may mutate
         rec, logvar, mu = model(existing.view(existing.shape), None if missing is None else missing.view(missing.shape),
                                 list(gt.shape), epoch, device, points=points, eps=eps_noise)
@@ -207,14 +242,17 @@ class TrainEngine:
             # the hypernetwork's gradients (90 % of the bytes) are complete once its backward has been
             # enqueued; ship them while the encoders' backward still runs
             self._install_overlap_hook()
-            if self.shard is not None:
-                ops.HEADS_DW_EXCHANGE = self.shard
-        elif self.fused is not None:
-            ops.HEADS_DW_EXCHANGE = self.fused
         try:
             torch.autograd.backward(roots, root_grads)
+        except BaseException:
+            if self.fused is not None:
+                self.fused.join()               # the side stream must not outlive the failed step
+            raise
         finally:
-            ops.HEADS_DW_EXCHANGE = None
+            model.hyper_network._heads_exchange = None
+            model._after_encoder_tails = None
+            if self.fused is not None:
+                self.fused.flush()              # (modes without the paired encoders' backward; a no-op otherwise)
             args, self._deferred_losses = self._deferred_losses, None
             if args is not None:
                 call("hp_step_losses", *args, current_stream(device))
@@ -227,7 +265,8 @@ class TrainEngine:
         if not self.exchange:
             # nothing to exchange: one pass over the flat buffer (minus the heads' weights when their update was fused
             # into the hypernetwork backward)
-            self._adam_range(self.fused.hi if self.fused is not None else 0, self.flat.total)
+            # (the heads are skipped only if their fused pass really ran for this step)
+            self._adam_range(self.fused.hi if (self.fused is not None and self.fused.ran) else 0, self.flat.total)
             if self.fused is not None:
                 self.fused.join()
             self._heads_pending = False

@@ -160,6 +160,7 @@ class HyperPocket(ModelMode):
                     eps = torch.randn((x0.size(0), re.output_size), dtype=torch.float32, device=x0.device)
                 side = _side_stream(model, missing.device) if model.concurrent_encoders else None
                 latent, mu, logvar = EncoderPairFunction.apply(x0, eps.contiguous(), x1, re.output_size, side,
+                                                               model.__dict__.get("_after_encoder_tails"),
                                                                *re._params(), *pe._params())
                 return latent, mu, logvar                    # latent = [codes | real_mu], written in place by the two encoders
             elif model.concurrent_encoders and missing.is_cuda:

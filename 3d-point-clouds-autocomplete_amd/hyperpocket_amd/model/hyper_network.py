@@ -46,4 +46,5 @@ class HyperNetwork(nn.Module):
         trunk = [self.model[i] for i in (0, 2, 4, 6, 8)]
         heads = list(self.output)
         params = [l.weight for l in trunk] + [l.bias for l in trunk] + [h.weight for h in heads] + [h.bias for h in heads]
-        return HyperNetFunction.apply(x, len(heads), *params)
+        # (the engine that drives this step may take over the heads' weight gradient: ops.py)
+        return HyperNetFunction.apply(x, len(heads), self.__dict__.get("_heads_exchange"), *params)

@@ -170,7 +170,7 @@ class EncoderPairFunction(Function):
     N_VAE = 16
 
     @staticmethod
-    def forward(ctx, x0, eps, x1, out_size, side, *params):
+    def forward(ctx, x0, eps, x1, out_size, side, after_tails, *params):
         p0, p1 = params[:EncoderPairFunction.N_VAE], params[EncoderPairFunction.N_VAE:]
         check_input(x0, "x (VAE encoder)")
         check_input(x1, "x (plain encoder)")
@@ -204,7 +204,7 @@ class EncoderPairFunction(Function):
             io[e].ws, io[e].is_vae, io[e].out_ld = ws.data_ptr(), int(vae), 2 * out_size
             keep.append((argidx, g, f, mu, lv, z, explv, ws))
         call("hp_encoder_forward_pair", B, Np, out_size, io, current_stream(dev))
-        ctx.out_size, ctx.side = out_size, side
+        ctx.out_size, ctx.side, ctx.after_tails = out_size, side, after_tails
         ctx.fwd_ws = [k[7] if KEEP_ENCODER_ACTIVATIONS else None for k in keep]
         ctx.save_for_backward(x0, eps, x1, keep[0][0], keep[0][1], keep[0][2], keep[0][4], keep[1][0], keep[1][1], keep[1][2],
                               *params)
@@ -247,9 +247,19 @@ class EncoderPairFunction(Function):
                 io[e].grad_out, io[e].grad_mu, io[e].grad_explv = gout.data_ptr(), _dp(gm), _dp(ge)
                 io[e].gr, io[e].ws, io[e].fwd_ws = ctypes.pointer(gr), ws.data_ptr(), _dp(fwd_ws)
                 io[e].is_vae, io[e].grad_out_ld = int(vae), 2 * ctx.out_size
-            call("hp_encoder_backward_pair", B, Np, ctx.out_size, io, int(DEDUP_CRITICAL_ROWS), current_stream(dev))
+            # `after_tails` (core/engine.py: the heads' fused dW + Adam pass): work of ANOTHER stream that should start
+            # behind the two tails' three launches — an HBM-saturating pass that occupies every CU would otherwise hold
+            # the tails' first launch back for its whole duration, while beside the matrix-bound conv-stack launches
+            # it costs little.  The library orders that stream behind the tails (event record + stream wait).
+            job, ctx.after_tails = ctx.after_tails, None
+            if job is not None and not job.pending():
+                job = None
+            call("hp_encoder_backward_pair_ordered", B, Np, ctx.out_size, io, int(DEDUP_CRITICAL_ROWS), current_stream(dev),
+                 ctypes.c_void_p(job.stream.cuda_stream) if job is not None else None)
+            if job is not None:
+                job.launch_ordered()
             ctx.fwd_ws = None
-            return (None, None, None, None, None, *out0, *out1)
+            return (None, None, None, None, None, None, *out0, *out1)
         # the two chains are independent: the VAE encoder's goes to the side stream
         if side is not cur:
             side.wait_stream(cur)
@@ -262,21 +272,22 @@ class EncoderPairFunction(Function):
                 if t is not None:
                     t.record_stream(side)
         ctx.fwd_ws = None
-        return (None, None, None, None, None, *out0, *out1)
+        return (None, None, None, None, None, None, *out0, *out1)
 
 
-# An object with `accepts(head_weights) -> bool`, `begin(grad_theta, t5)` and optionally `finish(grad_theta, t5)`
-# (core/engine.py: HeadsShard under data parallelism, FusedHeadsAdam on one GPU).  When set and accepting, the
-# hypernetwork backward leaves the heads' weight gradient to it: the ranks exchange the gradient's two factors
-# (d theta, t5) instead of the 156 MB matrix / one kernel forms the gradient and applies Adam without storing it.
-HEADS_DW_EXCHANGE = None
+# The heads' weight gradient may be left to an exchange object with `accepts(head_weights) -> bool`, `begin(grad_theta, t5)`
+# and optionally `finish(grad_theta, t5)` (core/engine.py: HeadsShard under data parallelism, FusedHeadsAdam on one GPU): the
+# ranks then exchange the gradient's two factors (d theta, t5) instead of the 156 MB matrix / one kernel forms the gradient
+# and applies Adam without storing it.  The object travels with the autograd node: HyperNetwork.forward reads it from its
+# module (`hyper_network._heads_exchange`, set by the engine for the forward of the step it drives) and hands it to
+# HyperNetFunction.apply — no process-global state, two engines in one process do not see each other's.
 
 
 class HyperNetFunction(Function):
     """model/hyper_network.py:41-43.  params: trunk_w x5, trunk_b x5, head_w x H, head_b x H."""
 
     @staticmethod
-    def forward(ctx, latent, n_heads, *params):
+    def forward(ctx, latent, n_heads, exchange, *params):
         latent = latent.contiguous()
         check_input(latent, "latent")
         # raw pointers go to the kernels: a head left on the CPU (`freeze_layers_learning` keeps `output` a plain list,
@@ -300,7 +311,7 @@ class HyperNetFunction(Function):
         t = torch.empty((_long_fn("hp_hypernet_saved_floats", B),), dtype=torch.float32, device=dev)
         theta = torch.empty((B, total), dtype=torch.float32, device=dev)
         call("hp_hypernet_forward", B, in_size, latent, ctypes.byref(w), t, theta, total, current_stream(dev))
-        ctx.n_heads = n_heads
+        ctx.n_heads, ctx.exchange = n_heads, exchange
         ctx.save_for_backward(latent, t, *params)
         return theta
 
@@ -312,7 +323,7 @@ class HyperNetFunction(Function):
         B, in_size = latent.shape
         dev = latent.device
         w, gr = _HyperWeights(), _HyperGrads()
-        exch = HEADS_DW_EXCHANGE
+        exch, ctx.exchange = ctx.exchange, None
         external_dw = exch is not None and exch.accepts(params[10:10 + n_heads])
         out = [None if external_dw and 10 <= i < 10 + n_heads else _grad_buffer(p) for i, p in enumerate(params)]
         for i in range(5):
@@ -334,7 +345,7 @@ class HyperNetFunction(Function):
             # in-place consumers of the heads' weights (the fused dW + Adam pass) go behind the backward that reads them
             o5 = _long_fn("hp_hypernet_t5_offset", B)
             exch.finish(grad_theta, t[o5:o5 + B * 2048].view(B, 2048))
-        return (grad_latent, None, *out)
+        return (grad_latent, None, None, *out)
 
 
 # The published decoder (3-32-64-128-64-3) runs as one fused kernel per direction (csrc/target_fused.hip: weights in

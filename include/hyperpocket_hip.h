@@ -243,6 +243,11 @@ typedef struct HpEncoderBwdIO {
     int grad_out_ld;
 } HpEncoderBwdIO;
 int hp_encoder_backward_pair(int B, int Np, int out_size, const HpEncoderBwdIO* io /* [2] */, int dedup, hpStream_t stream);
+/* ... with a second stream `after` (may be NULL) ordered behind the two tails' launches (an event recorded on `stream`, a
+ * wait on `after`): what the caller enqueues on `after` next starts when the tails are done and runs beside the conv-stack
+ * launches — the engine's HBM-bound heads dW + Adam pass, which would otherwise hold the tails' first launch back. */
+int hp_encoder_backward_pair_ordered(int B, int Np, int out_size, const HpEncoderBwdIO* io /* [2] */, int dedup, hpStream_t stream,
+                                     hpStream_t after);
 /* Parity-test switch: 0 sends every encoder backward through round 2's layered launch sequence (sort, gather, a dX GEMM,
  * a dW GEMM and a split-K reduce per layer), 1 (default) through the fused kernels when fwd_ws != NULL and dedup != 0.
  * Returns the previous setting. */
