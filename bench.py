@@ -148,6 +148,61 @@ def cpu_baseline(n_half, emd_coef, sample_b=4, timed_steps=2):
                       f"existing/missing ({sample_b},{n_half},3), gt ({sample_b},{2 * n_half},3); {dt:.2f} s/step"}
 
 
+def dropin_route(batch, n_half, device, steps, optimizer="torch"):
+    """The route the reference's own loop takes with the drop-in modules — /root/reference/core/epoch_loops.py:15-39 as
+    that file drives it, not the engine: per iteration `optimizer.zero_grad()`, the three inputs moved from pinned host
+    memory (the reference's DataLoaders are built with pin_memory=True, core/main.py:91) with `.to(device)`,
+    `full_model(existing, missing, list(gt.shape), epoch, device)`, `0.05 * ChamferLoss()(gt, rec.permute(0, 2, 1))`, the
+    KLD term in torch, three `.item()` host syncs, `loss.backward()`, `optimizer.step()`.  Chamfer-only: the
+    reference's training loss.  optimizer = "torch": torch.optim.Adam(full_model.parameters(), lr=1e-4) exactly as
+    core/main.py:62-66 builds it; "flat": hyperpocket_amd.optim.FlatAdam(full_model, lr=1e-4), the documented one-line
+    replacement.  Returns ms per iteration (host clock around `steps` iterations, device idle
+    before and after)."""
+    from hyperpocket_amd.core.setup import weights_init
+    from hyperpocket_amd.losses.champfer_loss import ChamferLoss
+    from hyperpocket_amd.model.full_model import FullModel
+    from hyperpocket_amd.optim import FlatAdam
+    torch.manual_seed(2020)
+    model = FullModel(copy.deepcopy(MODEL_CFG))
+    model.apply(weights_init)
+    model = model.to(device)
+    loss_fn = ChamferLoss().to(device)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4) if optimizer == "torch" else FlatAdam(model, lr=1e-4)
+    ex, mi, gt = (t.cpu().pin_memory() for t in synth_batch(batch, n_half, device, 2020))
+    model.train()
+    sums = [0.0, 0.0, 0.0]
+
+    def iteration():
+        opt.zero_grad()
+        e, m, g = ex.to(device), mi.to(device), gt.to(device)
+        rec, logvar, mu = model(e, m, list(g.shape), 1, device)
+        loss_r = torch.mean(0.05 * loss_fn(g, rec.permute(0, 2, 1)))
+        kld = torch.div(0.5 * (torch.exp(logvar) + torch.square(mu) - 1 - logvar).sum(), e.shape[0])
+        total = loss_r + kld
+        sums[0] += kld.item()
+        sums[1] += loss_r.item()
+        sums[2] += total.item()
+        total.backward()
+        opt.step()
+
+    for _ in range(5):
+        iteration()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        iteration()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    assert sums[2] == sums[2], "NaN loss on the drop-in route"
+    from hyperpocket_amd import ops
+    if optimizer != "torch":
+        model.hyper_network._heads_exchange = None
+        model._after_encoder_tails = None
+    del opt, model
+    ops.clear_grad_views()
+    return ms
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` outside torchrun: start N fresh ranks (one process per GPU) and relay their output.
     Nothing in this process has initialised HIP yet (importing torch does not), and it never does: the children are
@@ -460,6 +515,19 @@ def main():
                     engine.emd_coef = emd_coef
                     line["breakdown"] = {"chamfer_only_ms_per_step": round(ms2, 4),
                                          "chamfer_only_clouds_per_s": round(args.batch / (ms2 * 1e-3), 2)}
+                    # ... and the same Chamfer-only iteration on the route the reference's untouched core/epoch_loops.py
+                    # takes with the drop-in modules (host-pinned inputs, torch KLD, 3 x .item(), torch.optim.Adam), then
+                    # with the documented one-line optimiser replacement
+                    ms_t = dropin_route(args.batch, n_half, device, args.steps, "torch")
+                    ms_f = dropin_route(args.batch, n_half, device, args.steps, "flat")
+                    line["breakdown"]["dropin_route"] = {
+                        "what": "core/epoch_loops.py:15-39 with FullModel + ChamferLoss + the caller's optimiser, Chamfer-only "
+                                "(the reference's training loss), inputs .to(device) from pinned host memory, 3 x .item() per step",
+                        "torch_optim_adam_ms_per_step": round(ms_t, 4),
+                        "torch_optim_adam_clouds_per_s": round(args.batch / (ms_t * 1e-3), 2),
+                        "flat_adam_ms_per_step": round(ms_f, 4),
+                        "flat_adam_clouds_per_s": round(args.batch / (ms_f * 1e-3), 2),
+                        "engine_over_dropin": round(ms_t / ms2, 3), "engine_over_dropin_flat_adam": round(ms_f / ms2, 3)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n_half, emd_coef)
         print(json.dumps(line), flush=True)
