@@ -1,5 +1,6 @@
 /* Skinny-M layer programs (internal): the M = B <= 64 chains of the step — hypernetwork trunk (model/hyper_network.py:16-30),
- * encoder fc/mu/std tail (model/encoder.py:30-36) — as ONE persistent launch per direction.  See skinny.hip. */
+ * encoder fc/mu/std tail (model/encoder.py:30-36) — one launch per phase (layer), ordered by the kernel boundary.  See
+ * skinny.hip. */
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -41,7 +42,7 @@ typedef struct HpSkOp {
 
 typedef struct HpSkProgram {
     int nops;
-    HpSkOp op[HP_SK_MAX_OPS];   /* phases ascending; a grid-wide barrier separates consecutive phases */
+    HpSkOp op[HP_SK_MAX_OPS];   /* phases ascending; each phase is one launch (up to 8 ops), the kernel boundary orders them */
 } HpSkProgram;
 
 #ifdef __cplusplus

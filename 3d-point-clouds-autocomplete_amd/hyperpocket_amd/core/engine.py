@@ -7,6 +7,7 @@ overlapped RCCL all-reduce and the fused HIP Adam — and it never synchronises 
 reference does three `.item()` syncs per step, epoch_loops.py:32-36).
 """
 import ctypes
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -187,10 +188,28 @@ class TrainEngine:
         self._adam_step = 0        # the step number the Adam launches of the step in flight use (bias correction)
         self._heads_pending = False
         self._deferred_losses = None
-        model._pre_hypernet_hook = self.finish_pending     # FullModel.forward calls it right before the hypernetwork
-        # A reader of the parameters outside `step` (model.state_dict(), torch.save: core/main.py:164) must not see the
-        # hypernetwork one step behind the encoders or half-gathered rows: flush the deferred updates first.
-        self._sd_hook = model.register_state_dict_pre_hook(lambda *_: self.synchronize())
+        # The model only holds WEAK references to its engine (a dropped engine must not stay pinned — with its four flat
+        # 173 MB buffers — by the model's hooks), and a new engine on the same model takes the hooks over.
+        prev = model.__dict__.get("_engine_ref")
+        prev = prev() if prev is not None else None
+        if prev is not None:
+            prev.close()
+        me = weakref.ref(self)
+        model._engine_ref = me
+
+        def pre_hypernet():                                # FullModel.forward calls it right before the hypernetwork
+            e = me()
+            if e is not None:
+                e.finish_pending()
+
+        def pre_state_dict(*_):
+            # A reader of the parameters outside `step` (model.state_dict(), torch.save: core/main.py:164) must not see the
+            # hypernetwork one step behind the encoders or half-gathered rows: flush the deferred updates first.
+            e = me()
+            if e is not None:
+                e.synchronize()
+        model._pre_hypernet_hook = pre_hypernet
+        self._sd_hook = model.register_state_dict_pre_hook(pre_state_dict)
         self._consts = {}
         # the heads' update: sharded over the ranks (HeadsShard) when the layout allows it, else all-reduced like the rest
         self.shard = None
@@ -205,6 +224,18 @@ class TrainEngine:
         if self.exchange:
             # replicas start from rank 0's weights
             dist.broadcast(self.flat.flat, src=0, group=process_group)
+
+    def close(self):
+        """Detach from the model: remove the state_dict hook and the pre-hypernetwork hook (idempotent).  Called when another
+        engine attaches to the same model; the flat parameter layout stays (the parameters keep pointing at it)."""
+        self.finish_pending()
+        if self._sd_hook is not None:
+            self._sd_hook.remove()
+            self._sd_hook = None
+        ref = self.model.__dict__.get("_engine_ref")
+        if ref is not None and ref() is self:
+            self.model._pre_hypernet_hook = None
+            self.model._engine_ref = None
 
     def _after_hypernet_backward(self, *_):
         if self.shard is not None:

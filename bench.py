@@ -113,39 +113,57 @@ def roofline_dominant_kernel(batch, n_half):
     return {"bound": "mfma", "kernel": "gemm_kernel<128,128,4,2,16,4> (encoder conv5: M=B*1024, N=K=512, fp32 MFMA 32x32x2)",
             "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "traffic_source": "profiles/r02_pmc_gemm_conv5.json (rocprofv3 --pmc passes of this launch; not measured in this run)"
+            if traffic is not None else None,
             "avg_launch_ms": round(ms, 4), "flops_per_launch": flops,
             "algorithmic_bytes_per_launch": (2 * m * 512 + 512 * 512 + 512) * 4}
 
 
-def cpu_baseline(n_half, emd_coef, sample_b=4, timed_steps=2):
+def cpu_baseline(n_half, emd_coef, sample_b=4, timed_steps=2, full_b=64):
     """The oracle (oracle/hyperpocket_ref.py: torch-CPU restatement of the reference step + the C restatement of the
-    EMD kernels, kind "port") on a bounded sample of the SAME workload: `sample_b` clouds of the same per-cloud shape,
-    same loss terms, 1 warm-up + `timed_steps` timed steps."""
+    EMD kernels, kind "port") on bounded samples of the SAME workload (B = 4 and B = 64): `sample_b` clouds of
+    the same per-cloud shape and loss terms, 1 warm-up + `timed_steps` timed steps — the headline `value` — and, when the
+    host is fast enough for it to stay within ~30 s, one warm-up + one timed step at the metric's own batch `full_b`."""
     from oracle import hyperpocket_ref as ref
     # torch's CPU kernels stop scaling (and thrash across NUMA domains) far below a 256-core host: 16 threads
-    threads = min(16, os.cpu_count() or 1)
+    host_cores = os.cpu_count() or 1
+    threads = min(16, host_cores)
     torch.set_num_threads(threads)
     os.environ["OMP_NUM_THREADS"] = str(threads)      # the C EMD oracle parallelises over clouds
-    P = ref.init_params(2020)
-    opt = ref.Adam(P)
-    g = torch.Generator().manual_seed(2020)
-    ex = torch.rand(sample_b, n_half, 3, generator=g) - 0.5
-    mi = torch.rand(sample_b, n_half, 3, generator=g) - 0.5
-    gt = torch.cat([ex, mi], 1)
 
-    def one():
-        pts = torch.stack([ref.generate_points(1, 2 * n_half) for _ in range(sample_b)])   # CPU draws, as the reference
-        eps = torch.randn(sample_b, 128)
-        ref.train_step(P, opt, ex, mi, gt, pts, eps, emd_coef=emd_coef)
-    one()
-    t0 = time.perf_counter()
-    for _ in range(timed_steps):
+    def leg(b, steps):
+        P = ref.init_params(2020)
+        opt = ref.Adam(P)
+        g = torch.Generator().manual_seed(2020)
+        ex = torch.rand(b, n_half, 3, generator=g) - 0.5
+        mi = torch.rand(b, n_half, 3, generator=g) - 0.5
+        gt = torch.cat([ex, mi], 1)
+
+        def one():
+            pts = torch.stack([ref.generate_points(1, 2 * n_half) for _ in range(b)])   # CPU draws, as the reference
+            eps = torch.randn(b, 128)
+            ref.train_step(P, opt, ex, mi, gt, pts, eps, emd_coef=emd_coef)
         one()
-    dt = (time.perf_counter() - t0) / timed_steps
-    return {"value": round(sample_b / dt, 3), "unit": "clouds/s", "cores": threads, "kind": "port",
-            "sample": f"{timed_steps} timed steps (after 1 warm-up) of the oracle train step (0.05*Chamfer + KLD/B"
-                      f"{' + 0.05*EMD/N' if emd_coef else ''}, Adam) at B={sample_b}, "
-                      f"existing/missing ({sample_b},{n_half},3), gt ({sample_b},{2 * n_half},3); {dt:.2f} s/step"}
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        return (time.perf_counter() - t0) / steps
+
+    dt = leg(sample_b, timed_steps)
+    what = f"0.05*Chamfer + KLD/B{' + 0.05*EMD/N' if emd_coef else ''}, Adam"
+    out = {"value": round(sample_b / dt, 3), "unit": "clouds/s", "cores": threads, "host_cores": host_cores, "kind": "port",
+           "sample": f"{timed_steps} timed steps (after 1 warm-up) of the oracle train step ({what}) at B={sample_b}, "
+                     f"existing/missing ({sample_b},{n_half},3), gt ({sample_b},{2 * n_half},3); {dt:.2f} s/step; "
+                     f"{threads} threads of the host's {host_cores} cores"}
+    est = dt * full_b / sample_b * 2                   # 1 warm-up + 1 timed step, if a step scaled linearly with B
+    if full_b and full_b != sample_b and est <= 40.0:
+        dt_full = leg(full_b, 1)
+        out["at_metric_batch"] = {"value": round(full_b / dt_full, 3), "unit": "clouds/s", "batch": full_b,
+                                  "sample": f"1 timed step (after 1 warm-up) at B={full_b}; {dt_full:.2f} s/step"}
+    elif full_b and full_b != sample_b:
+        out["at_metric_batch"] = {"value": None, "batch": full_b,
+                                  "sample": f"skipped: ~{est:.0f} s estimated from the B={sample_b} leg (bound: 40 s)"}
+    return out
 
 
 def dropin_route(batch, n_half, device, steps, optimizer="torch"):
@@ -203,14 +221,36 @@ def dropin_route(batch, n_half, device, steps, optimizer="torch"):
     return ms
 
 
+def visible_gpus():
+    """Number of GPUs the ranks will see, WITHOUT initialising HIP in this process (torch.cuda.device_count() may fall
+    back to hipGetDeviceCount, which opens /dev/kfd; the ranks are then children of a GPU-initialised process — the
+    pattern to stay away from on this pool).  *_VISIBLE_DEVICES if set, else the KFD topology's nodes with SIMDs; None if
+    neither can be read (the ranks then fail by themselves with a clear message)."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+        return n
+    except OSError:
+        return None
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` outside torchrun: start N fresh ranks (one process per GPU) and relay their output.
-    Nothing in this process has initialised HIP yet (importing torch does not), and it never does: the children are
-    separate Python processes started through torch.distributed.run, no exec of a GPU-holding process."""
+    Nothing in this process has initialised HIP yet (importing torch does not), and it never does — the device count
+    comes from the environment / sysfs (visible_gpus) — : the children are separate Python processes started through
+    torch.distributed.run, no exec of a GPU-holding process."""
     if not os.environ.get("HP_BENCH_ONE_DEVICE") and os.environ.get("HP_BENCH_BACKEND", "nccl") == "nccl" \
             and "--rendezvous-only" not in sys.argv:
-        have = torch.cuda.device_count()          # counts devices without creating a HIP context
-        if have < n:
+        have = visible_gpus()                     # from the environment / sysfs: this launcher never touches HIP
+        if have is not None and have < n:
             print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
             return 2
     with socket.socket() as sk:
@@ -484,15 +524,17 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "train-step point-clouds/sec at B=64, N=2048 (Chamfer+EMD)" if not args.no_emd
-            else "train-step point-clouds/sec at B=64, N=2048 (Chamfer only)",
+            "metric": f"train-step point-clouds/sec at B={args.batch}, N={args.points} (Chamfer+EMD)" if not args.no_emd
+            else f"train-step point-clouds/sec at B={args.batch}, N={args.points} (Chamfer only)",
             "value": round(value, 2), "unit": "clouds/s", "n_gpus": world,
             "rccl_ranks": dist.get_world_size() if grouped else 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"HyperPocket 128+128 train step, B={args.batch}/GPU, existing/missing (B,{n_half},3), "
                                    f"gt (B,{args.points},3), loss 0.05*Chamfer + KLD/B" + ("" if args.no_emd else " + 0.05*EMD/N")
-                                   + ", Adam lr 1e-4; BASELINE.json configs[1] shape at the metric's B=64",
+                                   + ", Adam lr 1e-4; " + ("BASELINE.json configs[1] shape at the metric's B=64" if args.batch == 64
+                                                           else f"BASELINE.json configs[1] (3D-EPN chair, Chamfer+EMD) at B={args.batch}"
+                                                           if args.batch == 32 else f"the metric's shape at B={args.batch}"),
                        "global_batch": args.batch * world, "points": args.points, "parallelism": f"dp{world}",
                        "params": 43328515},
             "final_loss": loss,
@@ -529,7 +571,7 @@ def main():
                         "flat_adam_clouds_per_s": round(args.batch / (ms_f * 1e-3), 2),
                         "engine_over_dropin": round(ms_t / ms2, 3), "engine_over_dropin_flat_adam": round(ms_f / ms2, 3)}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(n_half, emd_coef)
+            line["cpu_baseline"] = cpu_baseline(n_half, emd_coef, full_b=args.batch)
         print(json.dumps(line), flush=True)
     if grouped:
         dist.barrier()

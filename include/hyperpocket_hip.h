@@ -280,9 +280,9 @@ int hp_hypernet_heads_dw_adam(int Kc, int rows, int r0, const float* dtheta_all,
                               float* W_rows, float* m_rows, float* v_rows, float lr, float beta1, float beta2, float eps,
                               int step, hpStream_t stream);
 
-/* The M = B <= 64 chains (hypernetwork trunk, encoder fc/mu/std tail) run as ONE persistent launch per direction
- * (csrc/skinny.hip: layers are phases separated by a grid-wide barrier) when their shapes allow, otherwise as tiled GEMM
- * launches.  Diagnostic switch for parity tests: 0 forces the GEMM launches, 1 the layer programs, -1 the default
+/* The M = B <= 64 chains (hypernetwork trunk, encoder fc/mu/std tail) run as skinny layer programs — ONE latency-built
+ * launch per phase (layer), ordered by the kernel boundary, no reduce launches: csrc/skinny.hip; the one-persistent-launch
+ * variant with a grid-wide barrier was measured and dropped — when their shapes allow, otherwise as tiled GEMM launches.  Diagnostic switch for parity tests: 0 forces the GEMM launches, 1 the layer programs, -1 the default
  * (on; HP_SKINNY=0 in the environment turns it off).  Returns the previous setting.  No reference counterpart. */
 int hp_skinny_set_enabled(int on);
 

@@ -246,3 +246,41 @@ def test_bench_gpus_n_spawns_n_ranks_and_reports_them():
 def test_bench_launcher_fails_when_a_rank_fails():
     rc, _ = _bench_launcher({"HP_BENCH_FAIL_RANK": "1"}, "--gpus", "2", "--rendezvous-only")
     assert rc != 0
+
+
+def test_engine_hooks_are_weak_and_move_to_the_latest_engine():
+    """The model holds only weak references to its TrainEngine: a second engine on the same model takes the hooks over
+    (the first one's state_dict hook is removed), and a dropped engine leaves no-op hooks behind instead of staying
+    pinned with its flat buffers."""
+    import copy
+    import gc
+    import bench
+    from hyperpocket_amd import ops
+    from hyperpocket_amd.core.engine import TrainEngine
+    from hyperpocket_amd.model.full_model import FullModel
+    try:
+        m = FullModel(copy.deepcopy(bench.MODEL_CFG))
+        a = TrainEngine(m, fuse_heads_adam=False)
+        b = TrainEngine(m, fuse_heads_adam=False)
+        assert a._sd_hook is None and m._engine_ref() is b
+        a.close()                                   # idempotent, and does not detach the current owner
+        assert m._engine_ref() is b
+        del a, b
+        gc.collect()
+        assert m._engine_ref() is None
+        m._pre_hypernet_hook()                      # no-ops now
+        assert len(m.state_dict()) > 0
+    finally:
+        ops.clear_grad_views()
+
+
+def test_bench_counts_gpus_without_touching_hip(monkeypatch):
+    import bench
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,5")
+    assert bench.visible_gpus() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpus() == 0
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    for var in ("ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.visible_gpus() in (None, 0) or bench.visible_gpus() >= 0     # sysfs, or unknown: never a HIP call

@@ -234,3 +234,21 @@ def test_approxmatch_oracle_variants_envelope(oracle_lib, b, n, m):
     for x, y in zip(g3, g0):
         err = np.abs(x - y)
         assert err.max() < 5e-3 and (err > 5e-5 + 1e-3 * np.abs(y)).mean() <= 2e-3
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    """The C restatement of the structural losses on ragged / degenerate shapes — (1,1,1), n = 1, m = 1, (2,1500,7),
+    n != m either way, sizes that are no multiple of any tile the reference uses — built with
+    -fsanitize=address,undefined and run on exactly sized heap buffers (oracle/sanitize_main.c).  The reference's own
+    kernels read xyz2 past m in that class of shapes (approxmatch.cu:179); the oracle the HIP kernels are held to must
+    not.  CPU only: GPU sanitizers are not available on this pool."""
+    import os
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    if shutil.which("gcc") is None and shutil.which("cc") is None:
+        pytest.skip("no C compiler")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "sanitize"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.count(": ok") == 9 and "BAD" not in r.stdout

@@ -1,8 +1,9 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): the numbers and rocprof summaries committed under profiles/ (round 2).
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; rm -rf $O; mkdir -p $O
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"
+R=$GRAFT_REPO_ROOT; O="$R/gpurun_out/final"; rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-B=/root/repo/bench.py
+B=$R/bench.py
 python3 $B > $O/bench_n1.json 2> $O/bench_n1.err
 python3 $B --no-emd --no-cpu-baseline > $O/bench_chamfer.json 2>/dev/null
 python3 $B --batch 32 --no-cpu-baseline --no-extras > $O/bench_b32.json 2>/dev/null   # BASELINE configs[1]: B=32, N=2048, Chamfer+EMD on one GPU
