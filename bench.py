@@ -123,7 +123,7 @@ def cpu_baseline(n_half, emd_coef, sample_b=4, timed_steps=2, full_b=64):
     """The oracle (oracle/hyperpocket_ref.py: torch-CPU restatement of the reference step + the C restatement of the
     EMD kernels, kind "port") on bounded samples of the SAME workload (B = 4 and B = 64): `sample_b` clouds of
     the same per-cloud shape and loss terms, 1 warm-up + `timed_steps` timed steps — the headline `value` — and, when the
-    host is fast enough for it to stay within ~30 s, one warm-up + one timed step at the metric's own batch `full_b`."""
+    host is fast enough for it to stay within ~60 s, one warm-up + one timed step at the metric's own batch `full_b`."""
     from oracle import hyperpocket_ref as ref
     # torch's CPU kernels stop scaling (and thrash across NUMA domains) far below a 256-core host: 16 threads
     host_cores = os.cpu_count() or 1
@@ -156,13 +156,13 @@ def cpu_baseline(n_half, emd_coef, sample_b=4, timed_steps=2, full_b=64):
                      f"existing/missing ({sample_b},{n_half},3), gt ({sample_b},{2 * n_half},3); {dt:.2f} s/step; "
                      f"{threads} threads of the host's {host_cores} cores"}
     est = dt * full_b / sample_b * 2                   # 1 warm-up + 1 timed step, if a step scaled linearly with B
-    if full_b and full_b != sample_b and est <= 40.0:
+    if full_b and full_b != sample_b and est <= 60.0:
         dt_full = leg(full_b, 1)
         out["at_metric_batch"] = {"value": round(full_b / dt_full, 3), "unit": "clouds/s", "batch": full_b,
                                   "sample": f"1 timed step (after 1 warm-up) at B={full_b}; {dt_full:.2f} s/step"}
     elif full_b and full_b != sample_b:
         out["at_metric_batch"] = {"value": None, "batch": full_b,
-                                  "sample": f"skipped: ~{est:.0f} s estimated from the B={sample_b} leg (bound: 40 s)"}
+                                  "sample": f"skipped: ~{est:.0f} s estimated from the B={sample_b} leg (bound: 60 s)"}
     return out
 
 
@@ -219,6 +219,29 @@ def dropin_route(batch, n_half, device, steps, optimizer="torch"):
     del opt, model
     ops.clear_grad_views()
     return ms
+
+
+class c_stdout_to_stderr:
+    """RCCL prints a version banner to the C-level stdout when a communicator is created; with C buffering it lands
+    BEHIND the JSON line at exit.  The contract is one JSON line on stdout: send fd 1 to stderr around group creation and
+    flush the C buffer before restoring it."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
 
 
 def visible_gpus():
@@ -464,8 +487,11 @@ def main():
                 opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
             except Exception:      # older binding: default stream priority
                 pass
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
-                                    pg_options=opts)
+            with c_stdout_to_stderr():
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                        pg_options=opts)
+                # the communicator (and RCCL's stdout banner) comes with the first collective: do it here, under the guard
+                dist.barrier()
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     else:
@@ -570,6 +596,37 @@ def main():
                         "flat_adam_ms_per_step": round(ms_f, 4),
                         "flat_adam_clouds_per_s": round(args.batch / (ms_f * 1e-3), 2),
                         "engine_over_dropin": round(ms_t / ms2, 3), "engine_over_dropin_flat_adam": round(ms_f / ms2, 3)}
+            if world == 1 and not force_exchange and os.environ.get("HP_BENCH_NO_EXCHANGE_PROBE") is None:
+                # what the multi-rank step's bookkeeping costs before a byte crosses a link: the same step in a ONE-rank RCCL
+                # group in which every collective really runs (broadcast, factor gathers, in-place weight gather, both
+                # all-reduces, the deferred waits) minus the plain step above.  N > 1 runs cannot separate it from the wire.
+                try:
+                    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                    os.environ.setdefault("MASTER_PORT", "29541")
+                    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+                    probe_guard = c_stdout_to_stderr().__enter__()      # (until the group is gone: the banner is lazy)
+                    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+                    engine.close()
+                    eng_x = TrainEngine(model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, loss_coef=0.05, emd_coef=emd_coef,
+                                        force_exchange=True)
+                    run(args.warmup, eng_x)
+                    eng_x.finish_pending()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    run(args.steps, eng_x)
+                    eng_x.finish_pending()
+                    torch.cuda.synchronize()
+                    ms_x = (time.perf_counter() - t1) / args.steps * 1e3
+                    line.setdefault("breakdown", {})["one_rank_rccl_exchange"] = {
+                        "ms_per_step": round(ms_x, 4), "exposed_comm_ms": round(ms_x - ms_per_step, 4),
+                        "what": "the multi-rank step (sharded heads update + bucketed all-reduces over RCCL) in a one-rank group "
+                                "minus the plain one-GPU step: bookkeeping of the exchange, no wire time"}
+                    dist.destroy_process_group()
+                except Exception as exc:      # (informational leg: never fail the line over it)
+                    line.setdefault("breakdown", {})["one_rank_rccl_exchange"] = {"error": repr(exc)[:200]}
+                finally:
+                    if "probe_guard" in locals():
+                        probe_guard.__exit__(None, None, None)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n_half, emd_coef, full_b=args.batch)
         print(json.dumps(line), flush=True)

@@ -219,3 +219,63 @@ def test_fused_heads_dw_adam_equals_dw_then_adam():
         call("hp_hypernet_heads_dw_adam", kc, rows, r0, dth, 19011, t5, w, m, v, 1e-4, 0.9, 0.999, 1e-8, step,
              current_stream(w.device))
         assert torch.equal(w, w2) and torch.equal(m, m2) and torch.equal(v, v2), (kc, r0, rows)
+
+
+def _one_rank_rccl_worker(port, out):
+    """A one-rank RCCL group in which every collective of the multi-rank step really runs: Chamfer+EMD steps with the
+    row-sharded heads update (factor all-gathers, hp_hypernet_heads_dw_adam on the rank's rows, IN-PLACE all-gather of the
+    updated rows: input aliases output) and with the flat all-reduce."""
+    import torch.distributed as dist
+    from hyperpocket_amd import ops
+    from hyperpocket_amd.core.engine import TrainEngine
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    ex, mi, gt, pts, eps = (t.cuda() for t in _data())
+    res = {}
+    for shard in (True, False):
+        model = _build()
+        eng = TrainEngine(model, emd_coef=0.05, force_exchange=True, shard_heads=shard)
+        assert eng.exchange and (eng.shard is not None) == shard
+        snaps = []
+        for _ in range(3):
+            eng.step(ex, mi, gt, 7, points=pts, eps_noise=eps)
+            eng.synchronize()
+            snaps.append({k: p.detach().cpu().clone() for k, p in model.named_parameters()})
+        res[shard] = snaps
+        eng.close()
+        ops.clear_grad_views()
+    torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_rccl_sharded_heads_equal_all_reduce():
+    """After the FIRST step the heads' weights of the two exchange modes are bit-identical (same d theta, same t5; the rows'
+    fused dW + Adam kernel equals dW-then-Adam bit for bit, and the in-place all-gather of the updated rows must not
+    disturb them); everything else — reached through d t5, whose GEMM is split differently when the heads' dW is left to
+    the exchange — and the later steps agree within Adam's sign-like sensitivity."""
+    import tempfile
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = os.path.join(tempfile.mkdtemp(), "res.pt")
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_one_rank_rccl_worker, args=(port, out))
+    p.start()
+    p.join(timeout=600)
+    assert p.exitcode == 0
+    res = torch.load(out)
+    os.remove(out)
+    a, b = res[True], res[False]
+    for k in a[0]:
+        if k.startswith("hyper_network.output") and k.endswith("weight"):
+            assert torch.equal(a[0][k], b[0][k]), k
+    for step in range(3):
+        for k in a[step]:
+            d = (a[step][k].double() - b[step][k].double()).abs()
+            assert d.max().item() <= 2.05e-4 * (step + 1), (step, k, d.max().item())
+            assert (d > 1e-5).double().mean().item() <= 2e-3, (step, k)
+            assert d.mean().item() <= 2e-6, (step, k)

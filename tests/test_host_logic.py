@@ -284,3 +284,59 @@ def test_bench_counts_gpus_without_touching_hip(monkeypatch):
     for var in ("ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         monkeypatch.delenv(var, raising=False)
     assert bench.visible_gpus() in (None, 0) or bench.visible_gpus() >= 0     # sysfs, or unknown: never a HIP call
+
+
+def _engine_worker(rank, world, port, out):
+    """A 3-rank gloo group on CPU: 19016 padded head rows do not divide by 3, so the engine must fall back from the
+    row-sharded heads update (HeadsShard) to the flat all-reduce — and that all-reduce must sum over the three ranks."""
+    import torch.distributed as dist
+    import copy
+    from hyperpocket_amd import ops
+    from hyperpocket_amd.core.engine import HeadsShard, TrainEngine
+    from hyperpocket_amd.core.setup import weights_init
+    from hyperpocket_amd.model.full_model import FullModel
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    torch.manual_seed(100 + rank)                     # different weights per rank: the constructor must broadcast rank 0's
+    model = FullModel(copy.deepcopy(model_config()))
+    model.apply(weights_init)
+    eng = TrainEngine(model)
+    ok = eng.exchange and eng.shard is None and eng.fused is None and not HeadsShard.usable(eng.flat, world)
+    first = eng.flat.flat[:1000].clone()
+    gathered = [torch.empty_like(first) for _ in range(world)]
+    dist.all_gather(gathered, first)
+    ok = ok and all(torch.equal(gathered[0], t) for t in gathered)
+    eng.flat.grad.fill_(float(rank + 1))
+    eng.reducer.launch_all()
+    eng.reducer.finish()
+    ok = ok and bool((eng.flat.grad == float(sum(range(1, world + 1)))).all())
+    if rank == 0:
+        out.put(ok)
+    ops.clear_grad_views()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_sizes_that_do_not_divide_the_heads_rows_fall_back_to_all_reduce():
+    import copy
+    from hyperpocket_amd import ops
+    from hyperpocket_amd.core.engine import HeadsShard
+    from hyperpocket_amd.model.full_model import FullModel
+    from hyperpocket_amd.parallel import FlatParameters
+    try:
+        flat = FlatParameters(FullModel(copy.deepcopy(model_config())))
+        assert flat.heads["rows"] == 19011 and flat.heads["pad_rows"] == 19016
+        assert [w for w in range(1, 9) if HeadsShard.usable(flat, w)] == [1, 2, 4, 8]
+    finally:
+        ops.clear_grad_views()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_engine_worker, args=(r, 3, port, out)) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    assert out.get(timeout=10)
