@@ -65,6 +65,14 @@ __device__ __forceinline__ float4 f4mask(const float4& h, const float4& v) {
     return make_float4(h.x > 0.f ? v.x : 0.f, h.y > 0.f ? v.y : 0.f, h.z > 0.f ? v.z : 0.f, h.w > 0.f ? v.w : 0.f);
 }
 
+#ifndef HP_EB_GWG
+#define HP_EB_GWG 4096
+#endif
+#ifndef HP_EB_GEB
+#define HP_EB_GEB 8
+#endif
+constexpr int kGatherRowWgs = HP_EB_GWG;    // persistent row workgroups per encoder (gather launch)
+
 // HP_EB_PROF: start / end / a tag of a workgroup, written by thread 0 (timing experiments; prof == NULL in production)
 struct Stamp {
     long long* p;
@@ -137,10 +145,10 @@ __global__ __launch_bounds__(512) void enc_bwd_prep_kernel(const HpEncBwdArgs a)
 // ---------------------------------------------------------------------------------------------------------------------
 // gather: delta4 rows and dW5 — chains of dependent memory round trips, hidden by occupancy
 // ---------------------------------------------------------------------------------------------------------------------
-// Workgroups [0, 512) of an encoder: dW5[c,:] = sum_b dg[b,c] * h4[b, argmax[b,c], :] (one-hot upstream of the max-pool),
+// Workgroups [kGatherRowWgs, kGatherRowWgs + 512) of an encoder: dW5[c,:] = sum_b dg[b,c] * h4[b, argmax[b,c], :] (one-hot upstream of the max-pool),
 // db5[c] = sum_b dg[b,c]: thread (q = tid & 127: 4 consecutive k, g = tid >> 7: cloud parity), the (argmax, dg) pairs of
 // 256 clouds at a time through LDS so that the h4 row loads are one round trip deep; even clouds + odd clouds.
-// Workgroups [512, 512 + B*32): sixteen rows each, ONE WAVE per row (cloud b, slot u), four rows per wave: delta4[row] = (h4[row] > 0) * sum over
+// Workgroups [0, kGatherRowWgs): four rows at a time, ONE WAVE per row (cloud b, slot u): delta4[row] = (h4[row] > 0) * sum over
 // the row's channels, ascending, of dg[b,c] * W5[c,:]; a lane owns 8 of the 512 columns; rows in [cnt, ru32(cnt)) are
 // written as zeros (the matrix-core launches run on whole 32-row blocks).
 __global__ __launch_bounds__(256) void enc_bwd_gather_kernel(const HpEncBwdArgs a) {
@@ -152,8 +160,8 @@ __global__ __launch_bounds__(256) void enc_bwd_gather_kernel(const HpEncBwdArgs 
     const HpEncBwdSide& s = a.e[z];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     Stamp stamp(a.prof ? a.prof + (long)id * 4 : nullptr, tid);
-    if (rest < 512) {
-        const int c = rest;
+    if (rest >= kGatherRowWgs) {      // (the uniform 11-us channel tasks behind the row tasks, whose length varies)
+        const int c = rest - kGatherRowWgs;
         stamp.type = 1;
         const int q = tid & 127, g = tid >> 7;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -185,16 +193,18 @@ __global__ __launch_bounds__(256) void enc_bwd_gather_kernel(const HpEncBwdArgs 
         }
         return;
     }
-    const int rg = rest - 512, b = rg >> 5;
-    const int cnt = s.crit.cnt[b];
-    if ((rg & 31) * 16 >= ru32(cnt)) return;
+    // row workgroups are PERSISTENT: kGatherRowWgs of them per encoder stride over the B*128 groups of four slots (a grid
+    // of one workgroup per group — 16K workgroups, two thirds of them dead — was bound by workgroup dispatch: ~50 us)
     stamp.type = 2;
-    const int* chan = s.crit.chan + (long)b * 512;
-    const float* dgb = s.dg + (long)b * 512;
     const float* w5 = s.W[4] + 4 * lane;
-    for (int j = 0; j < 4; ++j) {
-        const int u = (rg & 31) * 16 + 4 * j + w;      // (the four waves take neighbouring rows)
-        if (u >= ru32(cnt)) break;
+    for (int rg = rest; rg < a.B * 128; rg += kGatherRowWgs) {
+        // group rg = (slot group q = rg / B, cloud b = rg % B): a workgroup's groups are then spread over the slot range —
+        // only the first ~cnt/4 groups of a cloud are live — instead of all low or all high
+        const int b = rg % a.B, u = (rg / a.B) * 4 + w;      // (the four waves take neighbouring rows)
+        const int cnt = s.crit.cnt[b];
+        if (u >= ru32(cnt)) continue;
+        const int* chan = s.crit.chan + (long)b * 512;
+        const float* dgb = s.dg + (long)b * 512;
         float* dst = s.d[4] + ((long)b * 512 + u) * 512 + 4 * lane;
         if (u >= cnt) {
             *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(256) void enc_bwd_gather_kernel(const HpEncBwdArgs 
         const float* hr = s.h[4] + ((long)b * a.Np + s.crit.pt[(long)b * 512 + u]) * 512 + 4 * lane;
         const float4 h0 = *reinterpret_cast<const float4*>(hr), h1 = *reinterpret_cast<const float4*>(hr + 256);
         float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-        constexpr int EB = 4;
+        constexpr int EB = HP_EB_GEB;
         for (int i = i0; i < i1; i += EB) {      // (uniform per wave)
             int ch[EB];
             float g[EB];
@@ -799,7 +809,7 @@ int hp_enc_bwd_conv(const HpEncBwdArgs* a0, hipStream_t stream) {
     HpEncBwdArgs args = *a0;
     HpEncBwdArgs* a = &args;
     static const bool prof_on = getenv("HP_EB_PROF") != nullptr;
-    const long ngat = (long)(512 + (long)a->B * 32) * a->n, nblk = (long)a->B * 16 * a->n, ndw = (long)a->S * kRangeWgs * a->n;
+    const long ngat = (long)(512 + kGatherRowWgs) * a->n, nblk = (long)a->B * 16 * a->n, ndw = (long)a->S * kRangeWgs * a->n;
     auto arm = [&](long n, int per) {
         if (!prof_on) return;
         (void)hipMemsetAsync(prof_buffer(), 0, sizeof(long long) * per * n, stream);

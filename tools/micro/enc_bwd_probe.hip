@@ -62,7 +62,7 @@ int main(int argc, char** argv) {
     hipEvent_t ev[6];
     for (auto& e : ev) hipEventCreate(&e);
     double acc[5] = {0};
-    const long ngat = (long)(512 + (long)B * 32) * n, nblk = (long)B * 16 * n, ndw = (long)a.S * kRangeWgs * n;
+    const long ngat = (long)(512 + kGatherRowWgs) * n, nblk = (long)B * 16 * n, ndw = (long)a.S * kRangeWgs * n;
     for (int it = -3; it < reps; ++it) {
         hipEventRecord(ev[0]);
         hipLaunchKernelGGL(enc_bwd_prep_kernel, dim3(B, n), dim3(512), 0, 0, a);
