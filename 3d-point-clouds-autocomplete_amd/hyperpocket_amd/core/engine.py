@@ -188,6 +188,8 @@ class TrainEngine:
         self._adam_step = 0        # the step number the Adam launches of the step in flight use (bias correction)
         self._heads_pending = False
         self._deferred_losses = None
+        import os as _os
+        self._join_early = _os.environ.get("HP_HEADS_JOIN_AT_STEP_END", "0") == "1"
         # The model only holds WEAK references to its engine (a dropped engine must not stay pinned — with its four flat
         # 173 MB buffers — by the model's hooks), and a new engine on the same model takes the hooks over.
         prev = model.__dict__.get("_engine_ref")
@@ -298,7 +300,11 @@ class TrainEngine:
             # into the hypernetwork backward)
             # (the heads are skipped only if their fused pass really ran for this step)
             self._adam_range(self.fused.hi if (self.fused is not None and self.fused.ran) else 0, self.flat.total)
-            if self.fused is not None:
+            # The heads' pass (936 MB of HBM traffic whatever the batch: ~180 us) is joined where its result is next READ —
+            # `finish_pending`, right before the next step's hypernetwork forward — not here: at B = 64 it ends inside the
+            # encoders' backward anyway, at B = 32 the compute stream would otherwise idle ~130 us for it at the step end
+            # instead of starting the next step's encoder forward.  HP_HEADS_JOIN_AT_STEP_END=1 restores the early join.
+            if self.fused is not None and self._join_early:
                 self.fused.join()
             self._heads_pending = False
             return out
@@ -412,6 +418,8 @@ class TrainEngine:
 
     def finish_pending(self):
         """Complete the deferred hypernetwork updates (idempotent).  Call before reading the parameters outside `step`."""
+        if self.fused is not None:
+            self.fused.join()          # (one GPU: the fused dW + Adam pass of the heads, if still in flight)
         if self._heads_pending and self.shard is not None:
             self.reducer.wait("small")
             self._adam_range(self.shard.hi, self.flat.buckets[1][1])
