@@ -65,6 +65,13 @@ def synth_batch(b, n_half, device, seed):
     return ex, mi, torch.cat([ex, mi], 1)
 
 
+def latest_profile(suffix):
+    """profiles/rNN_<suffix> of the latest round that has it (name, path) — the committed rocprofv3 summaries."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return (os.path.basename(hits[-1]), hits[-1]) if hits else (None, None)
+
+
 def event_time_ms(fn, iters, warm=2):
     """Average duration of fn() measured with HIP events on the stream fn launches on (torch's current stream).
     The events bracket back-to-back launches, so a host-side pause longer than the queued work would be counted as
@@ -93,7 +100,7 @@ def roofline_dominant_kernel(batch, n_half):
     that runs the encoder's wide layers (M = B*1024 points).  One launch = layer 5 of one encoder:
     C(M x 512) = A(M x 512) W(512 x 512)^T + b.  Algorithmic flops = 2*M*512*512 (868 736 FLOP/point
     of which layer 5 is 2*512*512).  `traffic` (HBM bytes per launch) comes from the PMC passes recorded in
-    profiles/r02_pmc_gemm_conv5.json (FETCH_SIZE x2 correction + WRITE_SIZE), measured at B=64."""
+    profiles/rNN_pmc_gemm_conv5.json of the latest round (FETCH_SIZE x2 correction + WRITE_SIZE), measured at B=64."""
     from hyperpocket_amd.ops import gemm
     m = batch * n_half
     a = torch.randn(m, 512, device="cuda")
@@ -107,13 +114,13 @@ def roofline_dominant_kernel(batch, n_half):
     flops = 2.0 * m * 512 * 512
     achieved = flops / (ms * 1e-3) / 1e12
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_gemm_conv5.json")
-    if os.path.exists(pmc) and batch == 64 and n_half == 1024:
+    pmc_name, pmc = latest_profile("pmc_gemm_conv5.json")
+    if pmc and batch == 64 and n_half == 1024:
         traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
     return {"bound": "mfma", "kernel": "gemm_kernel<128,128,4,2,16,4> (encoder conv5: M=B*1024, N=K=512, fp32 MFMA 32x32x2)",
             "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-            "traffic_source": "profiles/r02_pmc_gemm_conv5.json (rocprofv3 --pmc passes of this launch; not measured in this run)"
+            "traffic_source": f"profiles/{pmc_name} (rocprofv3 --pmc passes of this launch; not measured in this run)"
             if traffic is not None else None,
             "avg_launch_ms": round(ms, 4), "flops_per_launch": flops,
             "algorithmic_bytes_per_launch": (2 * m * 512 + 512 * 512 + 512) * 4}
@@ -312,9 +319,10 @@ def rendezvous_only(args, world, rank):
         sys.exit(3)
 
 
-def _pmc_profile(name):
-    path = os.path.join(ROOT, "profiles", name)
-    return json.load(open(path)) if os.path.exists(path) else None
+def _pmc_profile(suffix):
+    """(name, contents) of the latest round's profiles/rNN_<suffix>, or (None, None)."""
+    name, path = latest_profile(suffix)
+    return (name, json.load(open(path))) if path else (None, None)
 
 
 def roofline_emd(batch, n):
@@ -323,12 +331,12 @@ def roofline_emd(batch, n):
     each (row, candidate-pair) costs a fixed instruction sequence, quarter-rate v_exp_f32 included.  Model: per kernel,
     the VALU instructions of the compiled inner loop priced at MI355X_MICROARCH.md's issue costs (transcendental 8,
     every other vector op 4 cycles per wave-instruction) x the wave-instructions one hp_emd_forward call executes
-    (profiles/r02_emd_issue_model.json, produced by tools/emd_issue_model.py from the shipped code object's ISA).
+    (profiles/rNN_emd_issue_model.json of the latest round, produced by tools/emd_issue_model.py from the shipped code object's ISA).
     achieved = those useful issue cycles / the call's duration measured live with HIP events; peak = issue cycles the
     chip has (1024 SIMDs x 2.4 GHz)."""
     from hyperpocket_amd._lib import call, current_stream, load_library
     import ctypes
-    model = _pmc_profile("r02_emd_issue_model.json")
+    model_name, model = _pmc_profile("emd_issue_model.json")
     lib = load_library()
     lib.hp_emd_partials_floats.restype = ctypes.c_long
     f32 = dict(dtype=torch.float32, device="cuda")
@@ -348,7 +356,7 @@ def roofline_emd(batch, n):
     if model and model.get("batch") == batch and model.get("n") == n:
         cyc = model["issue_cycles_per_call"]
         out.update({"achieved": round(cyc / (ms * 1e-3) / 1e12, 4), "frac": round(cyc / (ms * 1e-3) / 1e12 / PEAK_VALU_ISSUE_TCYC, 4),
-                    "issue_cycles_per_call": cyc, "model": "profiles/r02_emd_issue_model.json",
+                    "issue_cycles_per_call": cyc, "model": f"profiles/{model_name}",
                     "traffic": model.get("hbm_bytes_per_call")})
     else:
         out.update({"achieved": None, "frac": None, "traffic": None})
@@ -421,7 +429,7 @@ def chamfer_stress(args, world, rank, local_rank, grouped, device):
         flops = 8.0 * pairs                               # 3 sub, 3 mul, 2 add per pair; compares excluded
         alg_bytes = B * (2 * N * 12 + 2 * N * 8)          # (n+m)*12 B read + (n+m)*8 B written per cloud
         tf = flops / (ms_f * 1e-3) / 1e12
-        pmc = _pmc_profile("r02_pmc_chamfer_n8192.json")
+        _, pmc = _pmc_profile("pmc_chamfer_n8192.json")
         traffic = pmc["hbm_bytes_per_launch"] if pmc and pmc.get("batch") == B and pmc.get("n") == N else None
         line["roofline"] = {"bound": "valu", "kernel": "nn_distance_kernel (both directed passes of the Chamfer forward, one launch)",
                             "achieved": round(tf, 2), "peak": PEAK_F32_VALU_TFLOPS, "unit": "TFLOP/s",

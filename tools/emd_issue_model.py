@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """VALU-issue model of the EMD sweep family, from the ISA hipcc emits for csrc/emd.hip (runs without a GPU).
 
-    python tools/emd_issue_model.py [--batch 64] [--n 2048] > profiles/r02_emd_issue_model.json
+    python tools/emd_issue_model.py [--batch 64] [--n 2048] > profiles/r03_emd_issue_model.json
 
 The sweeps are bound by vector-instruction ISSUE (scalar-path candidates, no LDS/HBM pressure): every (row,
 candidate-pair) costs a fixed instruction sequence.  For each kernel instance one hp_emd_forward(grad1=NULL, grad2)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): the numbers and rocprof summaries committed under profiles/ (round 2).
+# Runs on the GPU box (gpurun): the numbers and rocprof summaries committed under profiles/ (per round: HP_ROUND, default r03).
 : "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"
 R=$GRAFT_REPO_ROOT; O="$R/gpurun_out/final"; rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""gpurun_out/final (tools/final_measure.sh) -> the round-2 summaries committed under profiles/."""
+"""gpurun_out/final (tools/final_measure.sh) -> the round's summaries committed under profiles/ (HP_ROUND, default r03)."""
 import csv, glob, json, os, shutil, subprocess, sys
 from collections import defaultdict
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 F = os.path.join(R, "gpurun_out", "final")
 P = os.path.join(R, "profiles")
 py = sys.executable
-RD = "r02"
+RD = os.environ.get("HP_ROUND", "r03")
+RN = RD.lstrip("r0")
 
 
 def per_kernel(d):
@@ -35,20 +36,20 @@ for src, dst in (("bench_n1.json", "bench_n1.json"), ("bench_chamfer.json", "ben
     shutil.copy(os.path.join(F, src), os.path.join(P, f"{RD}_{dst}"))
 summ = os.path.join(R, "tools", "summarize_profile.py")
 subprocess.check_call([py, summ, os.path.join(F, "step"), os.path.join(P, f"{RD}_step_kernel_stats.md"),
-                       "Round 2 — full step: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-extras "
+                       f"Round {RN} — full step: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-extras "
                        "--no-cpu-baseline (B=64, Chamfer+EMD; 7 engine steps, nothing else in the trace)", "7"])
 subprocess.check_call([py, summ, os.path.join(F, "roof"), os.path.join(P, f"{RD}_roofline_kernel_stats.md"),
-                       "Round 2 — roofline launch alone: rocprofv3 --kernel-trace --stats -- python3 bench.py --roofline-only "
+                       f"Round {RN} — roofline launch alone: rocprofv3 --kernel-trace --stats -- python3 bench.py --roofline-only "
                        "(encoder conv5: M=65536, N=K=512; 200 warm-up + 100 timed launches, back to back)", "1"])
 subprocess.check_call([py, summ, os.path.join(F, "stress"), os.path.join(P, f"{RD}_chamfer_n8192_kernel_stats.md"),
-                       "Round 2 — BASELINE configs[4] per-GPU shape: rocprofv3 --kernel-trace --stats -- python3 bench.py --workload "
+                       f"Round {RN} — BASELINE configs[4] per-GPU shape: rocprofv3 --kernel-trace --stats -- python3 bench.py --workload "
                        "chamfer-stress --steps 5 --warmup 2 --no-extras (B=64, N=8192, Chamfer forward+backward; 7 steps)", "7"])
 pm = os.path.join(R, "tools", "pmc_summary.py")
 subprocess.check_call([py, pm, os.path.join(P, f"{RD}_pmc_step_kernels.md"),
-                       "Round 2 — PMC view of every kernel of the step (bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline)",
+                       f"Round {RN} — PMC view of every kernel of the step (bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline)",
                        os.path.join(F, "step_pmc_FETCH_SIZE"), os.path.join(F, "step_pmc_WRITE_SIZE"), os.path.join(F, "step_pmc_BUSY")])
 subprocess.check_call([py, pm, os.path.join(P, f"{RD}_pmc_chamfer_n8192.md"),
-                       "Round 2 — PMC view of the Chamfer stress kernels (bench.py --workload chamfer-stress, B=64, N=8192)",
+                       f"Round {RN} — PMC view of the Chamfer stress kernels (bench.py --workload chamfer-stress, B=64, N=8192)",
                        os.path.join(F, "stress_pmc_FETCH_SIZE"), os.path.join(F, "stress_pmc_WRITE_SIZE"), os.path.join(F, "stress_pmc_BUSY")])
 
 # ---- dominant GEMM (roofline.traffic)
