@@ -18,6 +18,7 @@
 // not depend on the row), and the backward GEMMs run over B*512 rows instead of B*Np.
 #include "hp_common.h"
 #include "hp_gemm.h"
+#include "hp_conv_split.h"
 #include "hp_model.h"
 #include "hp_skinny.h"
 #include "hp_enc_bwd.h"
@@ -428,7 +429,8 @@ __global__ __launch_bounds__(256) void vae_head_bwd_kernel(long n, const float* 
     dlv[t] = (a * eps[t] + (gexplv ? gexplv[t] : 0.f)) * expf(lv[t]);
 }
 
-long enc_fwd_ws(long B, long Np) { return B * Np * (64 + 128 + 256 + 512 + 512); }
+// activations h1..h5 of every point, then the split area of conv_split.hip (f16 weight pieces, exponents, activation maxima)
+long enc_fwd_ws(long B, long Np) { return B * Np * (64 + 128 + 256 + 512 + 512) + HP_CS_AREA_FLOATS; }
 long enc_bwd_ws(long B, long out) {
     const long Rc = B * 512;
     return Rc * 4 + Rc * (64 + 128 + 256 + 512) * 2 + B * (2 * out + 4 * 512) + kSplitWs + 64 + (B * (5 * 512 + 4) + 16);
@@ -608,14 +610,29 @@ int encoder_forward_impl(int B, int Np, int out_size, int n, const HpEncoderIO* 
     h[1] = e0.ws;
     for (int l = 2; l <= 5; ++l) h[l] = h[l - 1] + R * kEnc[l - 1];
     const long sWs = dz(e0.ws, e1.ws);
-    const float* in = e0.x;
-    long sIn = dz(e0.x, e1.x);
-    for (int l = 1; l <= 4; ++l) {
-        TRY(op.lin_fwd(in, sIn, kEnc[l - 1], e0.w->conv_w[l - 1], dz(e0.w->conv_w[l - 1], e1.w->conv_w[l - 1]),
-                       e0.w->conv_b[l - 1], dz(e0.w->conv_b[l - 1], e1.w->conv_b[l - 1]), h[l], sWs, kEnc[l], (int)R, kEnc[l],
-                       kEnc[l - 1], n, true));
-        in = h[l];
-        sIn = sWs;
+    // The conv stack: split-f16 matrix-pipe layers (conv_split.hip) unless switched off (HP_CONV_SPLIT=0 / hp_conv_split_set),
+    // else the fp32 MFMA GEMMs.
+    const bool split = hp_conv_split_enabled();
+    float* area = h[5] + R * 512;
+    if (split) {
+        const float* W0[4] = {e0.w->conv_w[1], e0.w->conv_w[2], e0.w->conv_w[3], e0.w->conv_w[4]};
+        const float* W1[4] = {e1.w->conv_w[1], e1.w->conv_w[2], e1.w->conv_w[3], e1.w->conv_w[4]};
+        TRY(hp_conv_split_prep(n, W0, W1, area, sWs, stream));
+        TRY(hp_conv_split_layer1(n, e0.x, dz(e0.x, e1.x), e0.w->conv_w[0], dz(e0.w->conv_w[0], e1.w->conv_w[0]), e0.w->conv_b[0],
+                                 dz(e0.w->conv_b[0], e1.w->conv_b[0]), h[1], sWs, area, sWs, R, stream));
+        for (int l = 2; l <= 4; ++l)
+            TRY(hp_conv_split_layer(l, n, h[l - 1], sWs, e0.w->conv_b[l - 1], dz(e0.w->conv_b[l - 1], e1.w->conv_b[l - 1]), h[l], sWs,
+                                    area, sWs, R, 1, 0, nullptr, nullptr, 0, stream));
+    } else {
+        const float* in = e0.x;
+        long sIn = dz(e0.x, e1.x);
+        for (int l = 1; l <= 4; ++l) {
+            TRY(op.lin_fwd(in, sIn, kEnc[l - 1], e0.w->conv_w[l - 1], dz(e0.w->conv_w[l - 1], e1.w->conv_w[l - 1]),
+                           e0.w->conv_b[l - 1], dz(e0.w->conv_b[l - 1], e1.w->conv_b[l - 1]), h[l], sWs, kEnc[l], (int)R, kEnc[l],
+                           kEnc[l - 1], n, true));
+            in = h[l];
+            sIn = sWs;
+        }
     }
     // layer 5 (no ReLU) + max over points.  When a cloud's points are whole row tiles the max-pool is fused into the
     // GEMM epilogue: h5 (B*Np x 512) is never written; its slot in the workspace holds the per-tile partials.
@@ -627,19 +644,25 @@ int encoder_forward_impl(int B, int Np, int out_size, int n, const HpEncoderIO* 
     d5.M = (int)R; d5.N = 512; d5.K = 512; d5.batch = n;
     d5.flags = HP_GEMM_BIAS | HP_GEMM_COLMAX;
     d5.group_rows = Np;
-    const int tr = hp_gemm_tile_rows(&d5);
+    const int tr = split ? 128 : hp_gemm_tile_rows(&d5);
     long tail_off = -1;
     if (tr > 0 && Np % tr == 0) {
         const long tiles = R / tr;
         d5.cmax = h[5];
         d5.cidx = reinterpret_cast<int*>(h[5] + tiles * 512);
         if (R * 512 - up4(2 * tiles * 512) >= 4L * 64 * 512 + 8L * 64 * out_size) tail_off = up4(2 * tiles * 512);
-        TRY(hp_gemm_f32(&d5, stream));
+        if (split)
+            TRY(hp_conv_split_layer(5, n, h[4], sWs, d5.bias, d5.sBiasz, nullptr, sWs, area, sWs, R, 0, 1, d5.cmax, d5.cidx, Np, stream));
+        else
+            TRY(hp_gemm_f32(&d5, stream));
         hipLaunchKernelGGL(colmax_tiles_kernel, dim3(2, B, n), dim3(256), 0, stream, d5.cmax, d5.cidx, Np / tr, tr, 512, io[0].g,
                            io[0].argidx, sWs, io[n - 1].g, io[n - 1].argidx);
     } else {
-        TRY(op.lin_fwd(h[4], sWs, 512, e0.w->conv_w[4], d5.sBz, e0.w->conv_b[4], d5.sBiasz, h[5], sWs, 512, (int)R, 512, 512, n,
-                       false));
+        if (split)
+            TRY(hp_conv_split_layer(5, n, h[4], sWs, d5.bias, d5.sBiasz, h[5], sWs, area, sWs, R, 0, 0, nullptr, nullptr, 0, stream));
+        else
+            TRY(op.lin_fwd(h[4], sWs, 512, e0.w->conv_w[4], d5.sBz, e0.w->conv_b[4], d5.sBiasz, h[5], sWs, 512, (int)R, 512, 512, n,
+                           false));
         for (int z = 0; z < n; ++z)
             hipLaunchKernelGGL(colmax_kernel, dim3(512 / 64, B), dim3(256), 0, stream, h[5] + z * sWs, Np, 512, io[z].g,
                                io[z].argidx);

@@ -51,9 +51,11 @@ def current_stream(device=None):
     if _RAW_STREAM is not None:
         if device is None:
             idx = torch.cuda.current_device()
-        elif isinstance(device, int):
+        elif type(device) is int:
             idx = device
         else:
+            if isinstance(device, str):
+                device = torch.device(device)
             idx = device.index if device.index is not None else torch.cuda.current_device()
         return ctypes.c_void_p(_RAW_STREAM(idx))
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

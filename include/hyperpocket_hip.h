@@ -252,6 +252,10 @@ int hp_encoder_backward_pair_ordered(int B, int Np, int out_size, const HpEncode
  * a dW GEMM and a split-K reduce per layer), 1 (default) through the fused kernels when fwd_ws != NULL and dedup != 0.
  * Returns the previous setting. */
 int hp_encoder_backward_set_fused(int on);
+/* The encoders' conv stack (model/encoder.py:14-28) runs on the f16 matrix pipe with every fp32 operand split into two
+ * f16 pieces (three MFMA products per block; as close to fp64 as the fp32 fma chain — csrc/conv_split.hip).  0 sends it
+ * through the fp32 MFMA GEMMs instead (also: environment HP_CONV_SPLIT=0).  Returns the previous setting. */
+int hp_conv_split_set(int on);
 
 /* HyperNetwork.forward (model/hyper_network.py:41-43): latent (B,in) -> theta (B,theta_ld); t = saved trunk
  * activations (hp_hypernet_saved_floats floats) for the backward. */

@@ -180,6 +180,76 @@ def _encoder_vs_oracle(ref):
                 grad_close(p.grad, want)
 
 
+def _conv_stack_from_workspace(B, Np, x, params, split):
+    """hp_encoder_forward through the C ABI with our own workspace: returns h1..h4 (views of the workspace), g and argidx."""
+    import ctypes
+    from hyperpocket_amd import _lib, ops
+    lib = _lib.load_library()
+    f32 = dict(dtype=torch.float32, device="cuda")
+    argidx = torch.empty((B, 512), dtype=torch.int32, device="cuda")
+    g, f, mu = torch.empty((B, 512), **f32), torch.empty((B, 512), **f32), torch.empty((B, 128), **f32)
+    ws = torch.zeros((ops._long_fn("hp_encoder_forward_workspace_floats", B, Np),), **f32)
+    w = ops._encoder_struct(params)
+    prev = lib.hp_conv_split_set(int(split))
+    try:
+        _lib.call("hp_encoder_forward", B, Np, x, ctypes.byref(w), 128, 0, None, argidx, g, f, mu, None, None, None, ws,
+                  _lib.current_stream(x.device))
+        torch.cuda.synchronize()
+    finally:
+        lib.hp_conv_split_set(prev)
+    R, hs, off = B * Np, [], 0
+    for c in (64, 128, 256, 512):
+        hs.append(ws[off:off + R * c].view(R, c))
+        off += R * c
+    return hs, g, argidx
+
+
+@pytest.mark.parametrize("B,Np,xscale,wscale", [(4, 1024, 1.0, 1.0), (3, 300, 1.0, 1.0), (2, 2048, 1e-3, 0.05), (2, 1024, 300.0, 4.0),
+                                                (5, 37, 1.0, 1.0)])
+def test_conv_stack_split_f16_is_as_close_to_fp64_as_the_fp32_chain(B, Np, xscale, wscale):
+    """csrc/conv_split.hip forms the encoders' conv GEMMs (model/encoder.py:14-28) from two f16 pieces per fp32 operand on the
+    f16 matrix pipe.  The claim is fp32-chain accuracy, layer by layer: against an fp64 evaluation OF THE SAME fp32 INPUTS
+    (each layer is fed the kernel's own previous activation) its error may not exceed the fp32 MFMA path's by more than the
+    stated factors, over input / weight scales that push the activations from 1e-6 to 1e6 (the per-tensor and per-channel
+    power-of-two scales must carry them)."""
+    from hyperpocket_amd.model.encoder import Encoder
+    from hyperpocket_amd.core.setup import weights_init
+    torch.manual_seed(17)
+    enc = Encoder({"output_size": 128, "use_bias": True, "relu_slope": 0.2}, is_vae=False).apply(weights_init).cuda()
+    params = [p.detach().reshape(p.shape[0], -1).contiguous() if p.dim() == 3 else p.detach().contiguous() for p in enc._params()]
+    with torch.no_grad():
+        for i in range(5):
+            params[i].mul_(wscale)
+            torch.nn.init.uniform_(params[5 + i], -0.05 * wscale, 0.05 * wscale)
+    x = ((torch.rand(B, Np, 3, device="cuda") - 0.5) * xscale).contiguous()
+    got = {s: _conv_stack_from_workspace(B, Np, x, params, s) for s in (True, False)}
+    stats = {True: [], False: []}
+    for s in (True, False):
+        hs, g, argidx = got[s]
+        prev = x.view(B * Np, 3)
+        for l in range(4):
+            want = torch.relu(prev.double() @ params[l].double().t() + params[5 + l].double())
+            err = (hs[l].double() - want).abs()
+            scale = want.abs().max().item()
+            stats[s].append((err.pow(2).mean().sqrt().item() / scale, err.max().item() / scale))
+            prev = hs[l]
+        h5 = (prev.double() @ params[4].double().t() + params[9].double()).view(B, Np, 512)
+        want_g, want_arg = h5.max(dim=1)
+        # the pooled features: value within fp32 rounding of the fp64 max; the arg-max row attains it within the same bound
+        scale = want_g.abs().max().item()
+        assert (g.double() - want_g).abs().max().item() <= 2e-6 * scale, (s, "g")
+        at_arg = torch.gather(h5, 1, argidx.long().unsqueeze(1)).squeeze(1)
+        assert (at_arg - want_g).abs().max().item() <= 4e-6 * scale, (s, "argidx")
+    for l in range(4):
+        rms_s, max_s = stats[True][l]
+        rms_c, max_c = stats[False][l]
+        msg = f"layer {l + 1}: split rms {rms_s:.3e} max {max_s:.3e} | fp32 chain rms {rms_c:.3e} max {max_c:.3e} (of the layer's max)"
+        if l == 0:
+            assert torch.equal(got[True][0][0], got[False][0][0]), "layer 1 (K = 3) is the same fma chain on both paths"
+        assert rms_s <= 1.5 * rms_c + 1e-9 and max_s <= 2.5 * max_c + 1e-9, msg
+        assert max_s <= 2e-6, msg
+
+
 def test_encoder_backward_gather_equals_recompute():
     """The two sources of the critical rows' activations (copied out of the forward's workspace / recomputed from the
     gathered coordinates) give bit-identical parameter gradients."""
@@ -208,8 +278,10 @@ def test_encoder_backward_gather_equals_recompute():
             # keeps round 2's layered launches: same per-row arithmetic, another summation order of the weight gradients
             grad_close(grads[0][k], grads[1][k], tol=2e-5)
         # the layered launches alone: gather == recompute bit for bit
+        # (on the fp32 MFMA conv path: the recomputation is that chain, the split-f16 forward rounds differently)
         from hyperpocket_amd import _lib
         prev = _lib.load_library().hp_encoder_backward_set_fused(0)
+        prev_split = _lib.load_library().hp_conv_split_set(0)
         try:
             lay = []
             for keep in (True, False):
@@ -224,9 +296,10 @@ def test_encoder_backward_gather_equals_recompute():
                 lay.append({k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None})
         finally:
             _lib.load_library().hp_encoder_backward_set_fused(prev)
+            _lib.load_library().hp_conv_split_set(prev_split)
         for k in lay[0]:
             assert torch.equal(lay[0][k], lay[1][k]), k
-            assert torch.equal(lay[1][k], grads[1][k]), k     # the recompute path IS the layered one
+            grad_close(lay[1][k], grads[1][k], tol=2e-5)      # the recompute path IS the layered one (behind the other forward)
 
 
 @pytest.mark.parametrize("is_vae,B,Np", [(True, 4, 1024), (False, 3, 300), (True, 2, 1), (False, 2, 4000), (True, 64, 256),
@@ -290,7 +363,9 @@ def test_encoder_backward_distinct_critical_points_equal_per_channel_rows():
                 grads.append({k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None})
         for k in grads[0]:
             grad_close(grads[0][k], grads[1][k], tol=2e-5)           # dedup: fused (gather) vs layered (recompute)
-            assert torch.equal(grads[2][k], grads[3][k]), k          # per-channel rows: gather == recompute, bit for bit
+            # per-channel rows: gather == recompute up to the forward's rounding (the recomputation is the fp32 chain, the
+            # split-f16 forward rounds differently; bit for bit on the fp32 conv path: the gather_equals_recompute test)
+            grad_close(grads[2][k], grads[3][k], tol=2e-5)
             grad_close(grads[0][k], grads[2][k], tol=2e-5)
 
 
