@@ -118,16 +118,30 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x,
         bb[u] = b[c4 + u];
     }
     float m = 0.f;
-    for (long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4); row < R; row += (long)gridDim.x * 16) {
-        const float x0 = x[row * 3], x1 = x[row * 3 + 1], x2 = x[row * 3 + 2];
-        f32x4 o;
+    // 64 rows per block pass: 4 rows per thread with their coordinate loads in flight together
+    for (long base = (long)blockIdx.x * 64 + (threadIdx.x >> 4); base < R; base += (long)gridDim.x * 64) {
+        float xv[4][3];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float v = __builtin_fmaf(x2, w2[u], __builtin_fmaf(x1, w1[u], __builtin_fmaf(x0, w0[u], 0.f)));
-            o[u] = fmaxf(v + bb[u], 0.f);
-            m = fmaxf(m, o[u]);
+        for (int q = 0; q < 4; ++q) {
+            const long row = min(base + 16 * q, R - 1);
+            xv[q][0] = x[row * 3];
+            xv[q][1] = x[row * 3 + 1];
+            xv[q][2] = x[row * 3 + 2];
         }
-        *reinterpret_cast<f32x4*>(h + row * 64 + c4) = o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long row = base + 16 * q;
+            f32x4 o;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float v = __builtin_fmaf(xv[q][2], w2[u], __builtin_fmaf(xv[q][1], w1[u], __builtin_fmaf(xv[q][0], w0[u], 0.f)));
+                o[u] = fmaxf(v + bb[u], 0.f);
+            }
+            if (row < R) {
+                m = fmaxf(fmaxf(m, fmaxf(o[0], o[1])), fmaxf(o[2], o[3]));
+                *reinterpret_cast<f32x4*>(h + row * 64 + c4) = o;
+            }
+        }
     }
     m = hp::wave_max(m);
     if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
@@ -388,8 +402,8 @@ int hp_conv_split_prep(int n, const float* const* W0, const float* const* W1, fl
 
 int hp_conv_split_layer1(int n, const float* x, long sXz, const float* W, long sWz, const float* b, long sBz, float* h1, long sHz,
                          float* area0, long sArea, long R, hipStream_t stream) {
-    const long blocks = (R + 15) / 16;
-    hipLaunchKernelGGL(conv1_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048), n), dim3(256), 0, stream, x, sXz, W, sWz, b,
+    const long blocks = (R + 63) / 64;
+    hipLaunchKernelGGL(conv1_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024), n), dim3(256), 0, stream, x, sXz, W, sWz, b,
                        sBz, h1, sHz, reinterpret_cast<unsigned*>(area0) + 1, sArea, R);
     HP_RETURN_LAST_ERROR();
 }
