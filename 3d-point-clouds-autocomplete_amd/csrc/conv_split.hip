@@ -22,8 +22,12 @@
 //   The accumulator is unscaled by the exact factor 2^-(e_x + e_w[n]) before bias / ReLU.
 //
 // Kernel: 128 x 128 output tile per 4-wave workgroup (64 x 64 per wave), 32-deep k-tiles; the activation tile is loaded
-// as fp32 (16-byte loads), split in registers (v_cvt_pk_f16_f32 + v_fma_mix) and stored as two f16 LDS images, the weight
-// tile is copied from the pre-split f16 arrays; 80-byte LDS rows keep the ds_read_b128 fragment reads conflict-free.
+// as fp32 (16-byte loads), split in registers and stored as two f16 LDS images, the weight tile is copied from the pre-split
+// f16 arrays; swizzled 64-byte LDS rows keep the stage writes and the ds_read_b128 fragment reads conflict-free.
+// tools/micro/gemm_f16x2.hip holds the variants measured against this one (cross-tile software pipeline with a raw barrier,
+// double-buffered LDS, 256 x 128 and 128 x 256 tiles, the 16x16x32 MFMA shape): all within +-6 % — the kernel sits at the
+// ~0.9 PFLOP/s (executed f16) that cdna_hip_programming.md quotes as the ceiling of two-barrier 128^2 structures, at a clock
+// the chip holds at ~1.9 GHz under this load (GRBM_GUI_ACTIVE / 8 / time; MFMA busy 0.49 of those cycles).
 // Epilogues: bias + ReLU + store + max (layers 2-4), or the fused max-pool of gemm.hip's HP_GEMM_COLMAX (layer 5).
 // Layer 1 (K = 3) is a plain fma kernel in the k order of the general GEMM (bit-identical to it), which also forms max|h1|.
 #include "hp_common.h"
@@ -37,7 +41,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BN = 128, BK = 32, LDH = BK + 8;
+constexpr int BM = 128, BN = 128, BK = 32, ROW = BK;
 constexpr int kTarget = 14;   // scaled maxima land in [2^13, 2^14): hi cannot overflow (f16 max 65504)
 
 // exponent e of a float's frexp form v = f 2^e, f in [0.5, 1), from its bits (0 for zero / subnormal inputs)
@@ -173,10 +177,12 @@ struct CsParams {
 
 template <bool COLMAX>
 __global__ __launch_bounds__(256, 3) void conv_split_kernel(const CsParams p) {
-    __shared__ __attribute__((aligned(16))) _Float16 Ah[BM * LDH];
-    __shared__ __attribute__((aligned(16))) _Float16 Al[BM * LDH];
-    __shared__ __attribute__((aligned(16))) _Float16 Bh[BN * LDH];
-    __shared__ __attribute__((aligned(16))) _Float16 Bl[BN * LDH];
+    // four f16 images [rows][32 k] of 64-byte rows; 16-byte chunk c of row r lives at chunk c ^ ((r >> 2) & 3): the b64 / b128
+    // stage writes and the b128 fragment reads (16 lanes = 16 rows, one chunk) are bank-conflict-free without padding
+    __shared__ __attribute__((aligned(16))) _Float16 Ah[BM * ROW];
+    __shared__ __attribute__((aligned(16))) _Float16 Al[BM * ROW];
+    __shared__ __attribute__((aligned(16))) _Float16 Bh[BN * ROW];
+    __shared__ __attribute__((aligned(16))) _Float16 Bl[BN * ROW];
     // XCD-aware bijective remap of the tile id: the column tiles of one row panel run on one XCD (they share its L2 copy)
     const int nwg = gridDim.x;
     int bid = blockIdx.x;
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(256, 3) void conv_split_kernel(const CsParams p) {
     for (int e = 0; e < 4; ++e) {
         const int idx = tid + e * 256, row = idx >> 3, kq = idx & 7;
         pa[e] = X + (long)min(row0 + row, M - 1) * K + 4 * kq;
-        a_off[e] = row * LDH + 4 * kq;
+        a_off[e] = row * ROW + (((kq >> 1) ^ ((row >> 2) & 3)) << 3) + 4 * (kq & 1);
     }
     const _Float16* pbh[2];
     const _Float16* pbl[2];
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(256, 3) void conv_split_kernel(const CsParams p) {
         const int idx = tid + e * 256, row = idx >> 2, c = idx & 3;
         pbh[e] = Whi + (long)(col0 + row) * K + 8 * c;
         pbl[e] = Wlo + (long)(col0 + row) * K + 8 * c;
-        b_off[e] = row * LDH + 8 * c;
+        b_off[e] = row * ROW + ((c ^ ((row >> 2) & 3)) << 3);
     }
 
     f32x16 acc[2][2];
@@ -261,13 +267,15 @@ __global__ __launch_bounds__(256, 3) void conv_split_kernel(const CsParams p) {
             f16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int o = (wm * 64 + i * 32 + r) * LDH + 16 * t + 8 * h;
+                const int ar = wm * 64 + i * 32 + r;
+                const int o = ar * ROW + (((2 * t + h) ^ ((ar >> 2) & 3)) << 3);
                 ah[i] = *reinterpret_cast<const f16x8*>(&Ah[o]);
                 al[i] = *reinterpret_cast<const f16x8*>(&Al[o]);
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int o = (wn * 64 + j * 32 + r) * LDH + 16 * t + 8 * h;
+                const int br = wn * 64 + j * 32 + r;
+                const int o = br * ROW + (((2 * t + h) ^ ((br >> 2) & 3)) << 3);
                 bh[j] = *reinterpret_cast<const f16x8*>(&Bh[o]);
                 bl[j] = *reinterpret_cast<const f16x8*>(&Bl[o]);
             }
