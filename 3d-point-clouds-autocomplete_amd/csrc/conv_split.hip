@@ -378,6 +378,48 @@ __global__ __launch_bounds__(256, 3) void conv_split_kernel(const CsParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// stand-alone form (hp_gemm_f16x2_*): any fp32 X (M, K) and W (N, K)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long count, unsigned* __restrict__ amax) {
+    __shared__ float smax[4];
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    m = hp::wave_max(m);
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(amax, __float_as_uint(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]))));
+}
+
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ W, int N, int K, _Float16* __restrict__ hi,
+                                                         _Float16* __restrict__ lo, int* __restrict__ wexp) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const float* w = W + (long)row * K;
+    float v[8];
+    float m = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int k = lane + 64 * u;
+        v[u] = k < K ? w[k] : 0.f;
+        m = fmaxf(m, fabsf(v[u]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    const int e = kTarget - frexp_exp(__float_as_uint(m));
+    const float sc = pow2f(e);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int k = lane + 64 * u;
+        if (k < K) {
+            const float xs = v[u] * sc;
+            const _Float16 hh = (_Float16)xs;
+            hi[(long)row * K + k] = hh;
+            lo[(long)row * K + k] = (_Float16)(xs - (float)hh);
+        }
+    }
+    if (lane == 0) wexp[row] = e;
+}
+
 bool g_enabled = [] {
     const char* e = getenv("HP_CONV_SPLIT");
     return !(e && e[0] == '0');
@@ -439,5 +481,40 @@ int hp_conv_split_layer(int l, int n, const float* X, long sXz, const float* bia
         hipLaunchKernelGGL(conv_split_kernel<true>, dim3(tiles, n), dim3(256), 0, stream, p);
     else
         hipLaunchKernelGGL(conv_split_kernel<false>, dim3(tiles, n), dim3(256), 0, stream, p);
+    HP_RETURN_LAST_ERROR();
+}
+
+// ---- the split-f16 GEMM as a stand-alone primitive (bench.py's roofline leg, tests): C = act(X W^T + b), X (M, K), W (N, K)
+// fp32 of either sign; N % 128 == 0, K % 32 == 0, K <= 512.  ws: hp_gemm_f16x2_workspace_floats(N, K) floats.
+// prepare: max|X| and the split of W (what the producing layer's epilogue and conv_split_prep_kernel do inside the stack);
+// run: the conv_split_kernel launch alone.
+HP_API long hp_gemm_f16x2_workspace_floats(int N, int K) { return 8L + N + (long)N * K; }
+
+HP_API int hp_gemm_f16x2_prepare(long M, int N, int K, const float* X, const float* W, float* ws, hipStream_t stream) {
+    HP_CHECK_ARG(M > 0 && N > 0 && K > 0 && N % BN == 0 && K % BK == 0 && K <= 512 && X && W && ws);
+    if (hipMemsetAsync(ws, 0, 32, stream) != hipSuccess) return (int)hipGetLastError();
+    const long count = M * K;
+    const long blocks = (count + 256 * 16 - 1) / (256 * 16);
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, stream, X, count,
+                       reinterpret_cast<unsigned*>(ws));
+    hipLaunchKernelGGL(split_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, W, N, K, reinterpret_cast<_Float16*>(ws + 8 + N),
+                       reinterpret_cast<_Float16*>(ws + 8 + N) + (long)N * K, reinterpret_cast<int*>(ws + 8));
+    HP_RETURN_LAST_ERROR();
+}
+
+HP_API int hp_gemm_f16x2_run(long M, int N, int K, const float* X, const float* bias, float* C, int relu, const float* ws,
+                             hipStream_t stream) {
+    HP_CHECK_ARG(M > 0 && M < (1L << 31) && N > 0 && K > 0 && N % BN == 0 && K % BK == 0 && K <= 512 && X && bias && C && ws);
+    CsParams p{};
+    p.X = X;
+    p.Whi = reinterpret_cast<const _Float16*>(ws + 8 + N);
+    p.Wlo = p.Whi + (long)N * K;
+    p.wexp = reinterpret_cast<const int*>(ws + 8);
+    p.amax_in = reinterpret_cast<const unsigned*>(ws);
+    p.bias = bias;
+    p.C = C;
+    p.M = (int)M; p.N = N; p.K = K; p.relu = relu;
+    p.tiles_n = N / BN;
+    hipLaunchKernelGGL(conv_split_kernel<false>, dim3((unsigned)((M + BM - 1) / BM) * p.tiles_n, 1), dim3(256), 0, stream, p);
     HP_RETURN_LAST_ERROR();
 }

@@ -474,6 +474,29 @@ class _GemmDesc(ctypes.Structure):
                 ("dyn_count", c_void_p), ("dyn_kind", c_int)]
 
 
+class GemmF16x2:
+    """Test / bench hook over hp_gemm_f16x2_*: C = act(X W^T + b) on the f16 matrix pipe with every fp32 operand split into
+    two f16 pieces (csrc/conv_split.hip — the kernel the encoders' conv stack runs).  The constructor prepares (max|X|, the
+    pieces of W), `run()` is the GEMM launch alone."""
+
+    def __init__(self, X, W, bias, relu=False, out=None):
+        for t, n in ((X, "X"), (W, "W"), (bias, "bias")):
+            check_input(t, n)
+        self.M, self.K = X.shape
+        self.N = W.shape[0]
+        if W.shape[1] != self.K or bias.numel() != self.N:
+            raise HipExtensionError("GemmF16x2: X (M,K), W (N,K), bias (N)")
+        self.X, self.W, self.bias, self.relu = X, W, bias, int(relu)
+        self.ws = torch.empty((_long_fn("hp_gemm_f16x2_workspace_floats", self.N, self.K),), dtype=torch.float32, device=X.device)
+        self.C = out if out is not None else torch.empty((self.M, self.N), dtype=torch.float32, device=X.device)
+        call("hp_gemm_f16x2_prepare", c_long(self.M), self.N, self.K, X, W, self.ws, current_stream(X.device))
+
+    def run(self):
+        call("hp_gemm_f16x2_run", c_long(self.M), self.N, self.K, self.X, self.bias, self.C, self.relu, self.ws,
+             current_stream(self.X.device))
+        return self.C
+
+
 def gemm(A, B, bias=None, relu=False, trans_a=False, trans_b=True, mask=None, add=None, ksplit=1, rowsum=False, out=None,
          dyn_rows=None, dyn_k=None):
     """Thin test hook over hp_gemm_f32 for 2-D / 3-D (batched) fp32 tensors:

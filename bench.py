@@ -15,7 +15,7 @@ B=64 clouds per GPU, existing/missing (B,1024,3), gt (B,2048,3), fp32 ("Chamfer+
 value = clouds/s over all ranks (weak scaling: B per GPU fixed).
 
 One JSON line on rank 0; besides the contract keys it carries
-  roofline      the dominant kernel (fp32 MFMA GEMM of the encoder stack), timed live with HIP events
+  roofline      the widest matrix kernel (conv5 of the encoder stack on the f16 pipe, split fp32 operands), timed live with HIP events
   roofline_emd  the EMD sweep family (45 % of the step): VALU issue cycles of the compiled loops / measured time
   cpu_baseline  the oracle's torch-CPU restatement of the reference step timed on this box's cores
   breakdown     extra figures (Chamfer-only step, per-op times) — informational
@@ -52,6 +52,7 @@ MODEL_CFG = {
     "target_network_input": {"constant": False, "normalization": {"enable": True, "type": "progressive", "epoch": 100}},
 }
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+PEAK_F16_MFMA_TFLOPS = 2516.6    # MI355X_MICROARCH.md: dense f16/bf16 matrix peak (16 x the fp32 matrix rate)
 PEAK_F32_VALU_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector peak (64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak
 PEAK_VALU_ISSUE_TCYC = 1024 * 2.4e9 / 1e12   # SIMD issue cycles per second: 256 CUs x 4 SIMDs x 2.4 GHz (same guide)
@@ -96,30 +97,48 @@ def event_time_ms(fn, iters, warm=2):
 
 
 def roofline_dominant_kernel(batch, n_half):
-    """The kernel with the largest share of the step (profiles/): gemm_kernel<128,128,4,2,16,4>, the fp32-MFMA GEMM
-    that runs the encoder's wide layers (M = B*1024 points).  One launch = layer 5 of one encoder:
-    C(M x 512) = A(M x 512) W(512 x 512)^T + b.  Algorithmic flops = 2*M*512*512 (868 736 FLOP/point
-    of which layer 5 is 2*512*512).  `traffic` (HBM bytes per launch) comes from the PMC passes recorded in
-    profiles/rNN_pmc_gemm_conv5.json of the latest round (FETCH_SIZE x2 correction + WRITE_SIZE), measured at B=64."""
-    from hyperpocket_amd.ops import gemm
+    """The widest matrix kernel of the step: layer 5 of the encoders' conv stack, C(M x 512) = A(M x 512) W(512 x 512)^T + b with
+    M = B*1024 points (one encoder per launch here; the step batches both encoders into one launch of twice the tiles).
+    Round 3 moved it from the fp32 matrix pipe (gemm_kernel<128,128,4,2,16,4>, v_mfma_f32_32x32x2_f32, 0.79 of 157.3 TFLOP/s)
+    to csrc/conv_split.hip: each fp32 operand split into two f16 pieces, three f16 MFMA products per fp32-equivalent
+    product, fp32 accumulation, fp32-chain accuracy (tests/test_model_gpu.py).  Algorithmic flops = 2*M*512*512 (SURVEY §8d);
+    `achieved` is algorithmic TFLOP/s.  The roofline that bounds this kernel is the f16 matrix peak divided by the three
+    products it executes per algorithmic one — `peak`; `frac` = achieved / peak = executed f16 flops / f16 peak.
+    `vs_f32_mfma_peak` prices the same number against the fp32 matrix peak the previous kernel was bound by, and
+    `f32_mfma_kernel` is that previous kernel timed here on the same operands.
+    `traffic` (HBM bytes per launch) comes from the PMC passes recorded under profiles/ (FETCH_SIZE x2 correction +
+    WRITE_SIZE), measured at B=64."""
+    from hyperpocket_amd import ops
     m = batch * n_half
-    a = torch.randn(m, 512, device="cuda")
+    a = torch.randn(m, 512, device="cuda").abs_()
     w = torch.randn(512, 512, device="cuda") * 0.05
     b = torch.zeros(512, device="cuda")
     c = torch.empty(m, 512, device="cuda")
-    # 200 warm-up launches (~55 ms): the chip needs >20 ms of continuous load to reach the clock it then sustains — the
-    # state every kernel of a training run executes in (tools/roof_sweep.py: 20 warm-up launches read 112 TFLOP/s, 100,
-    # 400 or 2000 read 127 on the same box; the step time itself does not depend on the warm-up length)
-    ms = event_time_ms(lambda: gemm(a, w, bias=b, out=c), iters=100, warm=200)
+    # 200 warm-up launches: the chip needs >20 ms of continuous load to reach the clock it then sustains — the state every
+    # kernel of a training run executes in (tools/roof_sweep.py)
+    g = ops.GemmF16x2(a, w, b, relu=False, out=c)
+    ms = event_time_ms(g.run, iters=100, warm=200)
+    ms32 = event_time_ms(lambda: ops.gemm(a, w, bias=b, out=c), iters=50, warm=100)
     flops = 2.0 * m * 512 * 512
     achieved = flops / (ms * 1e-3) / 1e12
+    peak = PEAK_F16_MFMA_TFLOPS / 3.0
     traffic = None
     pmc_name, pmc = latest_profile("pmc_gemm_conv5.json")
     if pmc and batch == 64 and n_half == 1024:
-        traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
-    return {"bound": "mfma", "kernel": "gemm_kernel<128,128,4,2,16,4> (encoder conv5: M=B*1024, N=K=512, fp32 MFMA 32x32x2)",
-            "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+        rec = json.load(open(pmc))
+        if "conv_split" in rec.get("kernel", ""):
+            traffic = rec["hbm_bytes_per_launch"]
+    return {"bound": "mfma", "kernel": "conv_split_kernel<false> (encoder conv5: M=B*1024, N=K=512; fp32 operands as 2 f16 pieces, "
+                                       "3 x v_mfma_f32_32x32x16_f16 per 32x32x16 block of products, fp32 accumulate)",
+            "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4),
+            "peak_is": f"f16 dense MFMA peak {PEAK_F16_MFMA_TFLOPS} TFLOP/s / 3 products per fp32-equivalent product",
+            "executed_f16_tflops": round(3 * achieved, 1),
+            "vs_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 3),
+            "f32_mfma_kernel": {"kernel": "gemm_kernel<128,128,4,2,16,4> (v_mfma_f32_32x32x2_f32)", "avg_launch_ms": round(ms32, 4),
+                                "achieved": round(flops / (ms32 * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                                "frac": round(flops / (ms32 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+            "traffic": traffic,
             "traffic_source": f"profiles/{pmc_name} (rocprofv3 --pmc passes of this launch; not measured in this run)"
             if traffic is not None else None,
             "avg_launch_ms": round(ms, 4), "flops_per_launch": flops,

@@ -180,6 +180,30 @@ def _encoder_vs_oracle(ref):
                 grad_close(p.grad, want)
 
 
+@pytest.mark.parametrize("M,N,K,relu", [(1000, 128, 64, True), (4096, 512, 512, False), (77, 256, 96, True), (1, 128, 32, False),
+                                        (3001, 384, 256, True)])
+def test_gemm_f16x2_standalone_vs_fp64(M, N, K, relu):
+    """The split-f16 GEMM as a primitive (hp_gemm_f16x2_*): operands of either sign, ragged M, against fp64 — error bars
+    those of an fp32 dot product (2e-6 of the output scale), and next to the fp32 MFMA GEMM of gemm.hip on the same data."""
+    from hyperpocket_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    X = torch.randn(M, K, device="cuda", generator=g) * torch.exp(2.0 * torch.randn(M, 1, device="cuda", generator=g))
+    W = (torch.rand(N, K, device="cuda", generator=g) - 0.5) * torch.exp(torch.randn(N, 1, device="cuda", generator=g))
+    b = torch.randn(N, device="cuda", generator=g)
+    got = ops.GemmF16x2(X, W, b, relu=relu).run()
+    want = X.double() @ W.double().t() + b.double()
+    chain = ops.gemm(X, W, bias=b, relu=relu)
+    if relu:
+        want = torch.relu(want)
+    # per output row: error relative to that row's scale (rows differ by e^(+-4) in magnitude here)
+    scale = want.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+    err = ((got.double() - want).abs() / scale).max().item()
+    err_chain = ((chain.double() - want).abs() / scale).max().item()
+    # the per-TENSOR activation scale costs small rows precision the per-row fp32 chain keeps: rows 2^-28 below the largest
+    # would lose bits; here rows span e^(+-4) ~ 2^(+-6) and must stay at fp32 level
+    assert err <= 2e-6 and err <= 3 * err_chain + 1e-7, (err, err_chain)
+
+
 def _conv_stack_from_workspace(B, Np, x, params, split):
     """hp_encoder_forward through the C ABI with our own workspace: returns h1..h4 (views of the workspace), g and argidx."""
     import ctypes

@@ -53,13 +53,13 @@ subprocess.check_call([py, pm, os.path.join(P, f"{RD}_pmc_chamfer_n8192.md"),
                        os.path.join(F, "stress_pmc_FETCH_SIZE"), os.path.join(F, "stress_pmc_WRITE_SIZE"), os.path.join(F, "stress_pmc_BUSY")])
 
 # ---- dominant GEMM (roofline.traffic)
-k = "gemm_kernel<128, 128, 4, 2, 16, 4>"
+k = "conv_split_kernel<false>"
 fe, n, _ = one("roof_pmc_FETCH_SIZE", k)
 wr, _, _ = one("roof_pmc_WRITE_SIZE", k)
 bu, _, us = one("roof_pmc_BUSY", k)
 rd = fe["FETCH_SIZE"] * 1024 * 2
 out = {
-    "kernel": "gemm_kernel<128,128,4,2,16,4> (fp32 MFMA 32x32x2, encoder conv5 shape M=65536 N=512 K=512, plain C store)",
+    "kernel": "conv_split_kernel<false> (split-f16 MFMA 32x32x16 x3, encoder conv5 shape M=65536 N=512 K=512, plain C store)",
     "command": "rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python3 bench.py --roofline-only   (one pass per "
                "counter group: FETCH_SIZE | WRITE_SIZE | GRBM_GUI_ACTIVE SQ_*; tools/final_measure.sh)",
     "launches_averaged": n, "FETCH_SIZE_KB_raw": round(fe["FETCH_SIZE"], 1),
@@ -69,6 +69,7 @@ out = {
     "algorithmic_bytes_per_launch": (2 * 65536 * 512 + 512 * 512 + 512) * 4,
     "GRBM_GUI_ACTIVE_sum_over_8_xcd": bu["GRBM_GUI_ACTIVE"], "SQ_VALU_MFMA_BUSY_CYCLES": bu["SQ_VALU_MFMA_BUSY_CYCLES"],
     "mfma_pipe_busy_frac": round(bu["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * bu["GRBM_GUI_ACTIVE"] / 8), 4),
+    "mfma_pipe_busy_is": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles): the fraction of the f16 matrix pipe's cycles AT THE CLOCK THE CHIP HELD",
     "clock_GHz_in_profiled_pass": round(bu["GRBM_GUI_ACTIVE"] / 8 / (us * 1e-6) / 1e9, 3),
     "note": "profiled passes run at a lower clock than un-profiled ones; compare fractions, not times",
 }
