@@ -39,6 +39,8 @@ class FlatAdam(torch.optim.Optimizer):
         super().__init__(list(model.parameters()), dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
         self.exp_avg = torch.zeros_like(self.flat.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat.flat)
+        self._param_ptrs = [self.flat.flat.data_ptr() + 4 * o for o in self.flat.offsets]
+        self._grad_ptrs = [self.flat.grad.data_ptr() + 4 * o for o in self.flat.offsets]
         self.steps = 0
         self._adam_step = 1        # the step number the launches of the iteration in flight use (bias correction)
         self.fused = None
@@ -71,18 +73,22 @@ class FlatAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        if not self.flat.is_intact():
-            raise RuntimeError("FlatAdam: parameters were re-allocated (e.g. model.to()) after the optimiser was built")
         flat = self.flat
+        # (the per-parameter checks below run every iteration of the caller's loop: plain integer compares against the
+        #  addresses computed once in __init__, no tensor views unless something has to be copied or zeroed)
+        for p, want in zip(flat.params, self._param_ptrs):
+            if p.data_ptr() != want:
+                raise RuntimeError("FlatAdam: parameters were re-allocated (e.g. model.to()) after the optimiser was built")
         # a gradient produced outside the HIP autograd nodes (or accumulated into a fresh tensor) is copied into its slot;
         # a parameter without gradient contributes zeros (torch.optim.Adam skips it: with zero moments the update is zero)
-        for p, o in zip(flat.params, flat.offsets):
-            slot = flat.grad[o:o + p.numel()]
-            if p.grad is None:
-                if not (self.fused is not None and self.fused.lo <= o < self.fused.hi and self.fused.ran):
-                    slot.zero_()
-            elif p.grad.data_ptr() != slot.data_ptr():
-                slot.copy_(p.grad.reshape(-1))
+        fused = self.fused
+        for p, o, want in zip(flat.params, flat.offsets, self._grad_ptrs):
+            g = p.grad
+            if g is None:
+                if not (fused is not None and fused.lo <= o < fused.hi and fused.ran):
+                    flat.grad[o:o + p.numel()].zero_()
+            elif g.data_ptr() != want:
+                flat.grad[o:o + p.numel()].copy_(g.reshape(-1))
         lo = 0
         if self.fused is not None:
             self.fused.flush()          # (a backward without the paired encoders' node: launch the pass now)
