@@ -108,6 +108,7 @@ struct Ctx {
     float* temp;  // (b, 2(n+m)) : [remainL n | remainR m | ratioL n | ratioR m]  (reference layout, approxmatch.cu:35)
     float* ws;
     long plp, prp, rr, flp, frp, per_cloud;
+    float acc_scale = 0.f;   // != 0: emd_grad2_kernel stores grad2[i] += acc_scale * d cost / d xyz2[i] instead of the plain gradient
 };
 
 // element offsets of candidate i inside the pair-record arrays
@@ -627,9 +628,15 @@ __global__ __launch_bounds__(kThreads) void emd_grad2_kernel(Ctx c, float* __res
             }
             if (ok[r]) {
                 float* g = grad2 + ((long)cloud * c.m + l[r]) * 3;
-                g[0] = sx[r];
-                g[1] = sy[r];
-                g[2] = sz[r];
+                if (c.acc_scale != 0.f) {   // hp_emd_forward_acc: the caller's running gradient (+= coef * this term)
+                    g[0] = __builtin_fmaf(c.acc_scale, sx[r], g[0]);
+                    g[1] = __builtin_fmaf(c.acc_scale, sy[r], g[1]);
+                    g[2] = __builtin_fmaf(c.acc_scale, sz[r], g[2]);
+                } else {
+                    g[0] = sx[r];
+                    g[1] = sy[r];
+                    g[2] = sz[r];
+                }
                 total += cost[r];
             }
         }
@@ -855,14 +862,41 @@ HP_API long hp_emd_partials_floats(int b, int n, int m) { return (long)b * ((std
 
 // grad1 / grad2 (either may be NULL): gradients to produce in the same call.  With grad2 != NULL the cost rides on the
 // grad2 sweep (one evaluation of the match entries serves both); grad1 then costs a second sweep only if requested.
+namespace {
+int emd_forward_impl(int b, int n, int m, const float* xyz1, const float* xyz2, float* temp, float* ws, float* partials,
+                     float* cost, float* grad1, float* grad2, float acc_scale, hipStream_t stream, hipStream_t after);
+}
 HP_API int hp_emd_forward(int b, int n, int m, const float* xyz1, const float* xyz2, float* temp, float* ws, float* partials,
                           float* cost, float* grad1, float* grad2, hipStream_t stream) {
+    return emd_forward_impl(b, n, m, xyz1, xyz2, temp, ws, partials, cost, grad1, grad2, 0.f, stream, nullptr);
+}
+
+// The training step's form: grad2_acc (b,m,3) already holds the other loss terms' gradient with respect to xyz2 (the Chamfer
+// term, written on stream `after`, or NULL = same stream) and receives  += scale * d cost / d xyz2  from the gradient sweep
+// itself — the caller's separate `g_rec.add_(g_emd, alpha=scale)` launch (core/epoch_loops.py:26-31 forms the sum through
+// autograd) is gone.  The sweep launch is ordered behind everything enqueued on `after` so far; scale != 0.
+HP_API int hp_emd_forward_acc(int b, int n, int m, const float* xyz1, const float* xyz2, float* temp, float* ws, float* partials,
+                              float* cost, float* grad2_acc, float scale, hipStream_t stream, hipStream_t after) {
+    HP_CHECK_ARG(grad2_acc && scale != 0.f);
+    return emd_forward_impl(b, n, m, xyz1, xyz2, temp, ws, partials, cost, nullptr, grad2_acc, scale, stream, after);
+}
+
+namespace {
+int emd_forward_impl(int b, int n, int m, const float* xyz1, const float* xyz2, float* temp, float* ws, float* partials,
+                     float* cost, float* grad1, float* grad2, float acc_scale, hipStream_t stream, hipStream_t after) {
     HP_CHECK_ARG(b >= 0 && n > 0 && m > 0);
     if (b == 0) return 0;
     HP_CHECK_ARG(xyz1 && xyz2 && temp && ws && partials && cost && b <= 65535);
     Ctx c;
     int rc = run_levels(b, n, m, xyz1, xyz2, temp, ws, &c, stream, false);   // temp is scratch here
     if (rc) return rc;
+    c.acc_scale = acc_scale;
+    if (after && after != stream) {   // the accumulated-into gradient was written on `after`: order the sweep behind it
+        static hipEvent_t ev = nullptr;
+        if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+        if (hipEventRecord(ev, after) != hipSuccess) return (int)hipGetLastError();
+        if (hipStreamWaitEvent(stream, ev, 0) != hipSuccess) return (int)hipGetLastError();
+    }
     const int nb = (n + kRowsPerWg - 1) / kRowsPerWg, mb = (m + kRowsPerWg - 1) / kRowsPerWg;
     if (grad2) {
         const int genv = g_grad2.load(std::memory_order_relaxed);
@@ -884,6 +918,8 @@ HP_API int hp_emd_forward(int b, int n, int m, const float* xyz1, const float* x
     }
     HP_RETURN_LAST_ERROR();
 }
+
+}  // namespace
 
 // grad2 = d cost / d xyz2 (b,m,3) from the records hp_emd_forward left in `ws` (match_cost.py:35-46 without match)
 HP_API int hp_emd_backward(int b, int n, int m, const float* xyz1, const float* xyz2, const float* ws, float* grad2,

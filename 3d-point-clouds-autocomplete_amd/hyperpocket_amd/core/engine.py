@@ -384,11 +384,11 @@ class TrainEngine:
             ws = torch.empty((max(1, lib.hp_approxmatch_workspace_floats(B, N, N)),), **f32)
             epart = torch.empty((max(1, lib.hp_emd_partials_floats(B, N, N)),), **f32)
             cost = torch.empty((B,), **f32)
-            g_emd = torch.empty_like(rec_c)
-            # match_cost(gt, reconstruction): cost and d cost / d reconstruction from the same sweeps
-            call("hp_emd_forward", B, N, N, gt_c, rec_c, temp, ws, epart, cost, None, g_emd, current_stream(dev))
-            cur.wait_stream(side)
-            g_rec.add_(g_emd, alpha=c_emd)
+            # match_cost(gt, reconstruction): cost and d cost / d reconstruction from the same sweeps; the gradient sweep adds
+            # c_emd * (its term) onto the Chamfer gradient the side stream left in g_rec, behind an event on that stream
+            # (which also joins the KLD gradients): no axpy launch, no separate stream join
+            call("hp_emd_forward_acc", B, N, N, gt_c, rec_c, temp, ws, epart, cost, g_rec, float(c_emd), current_stream(dev),
+                 ctypes.c_void_p(side.cuda_stream))
         terms = torch.empty((4,), **f32)
         # the scalar loss terms are nobody's input: their launch is deferred behind the backward's launches (step()), so it
         # does not sit between the EMD and the first backward kernel

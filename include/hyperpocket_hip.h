@@ -64,6 +64,11 @@ int hp_emd_set_rows_per_lane(int rows1, int rows2, int grad2);
 long hp_emd_partials_floats(int b, int n, int m);
 int hp_emd_forward(int b, int n, int m, const float* xyz1, const float* xyz2, float* temp, float* ws, float* partials,
                    float* cost, float* grad1 /* or NULL */, float* grad2 /* or NULL */, hpStream_t stream);
+/* The training step's form of hp_emd_forward: grad2_acc (b,m,3) already holds the gradient of the other loss terms with respect
+ * to xyz2 (written on stream `after`; NULL = the same stream) and receives += scale * d cost / d xyz2 from the gradient sweep
+ * itself (no separate axpy launch); the sweep is ordered behind everything enqueued on `after` so far.  scale != 0. */
+int hp_emd_forward_acc(int b, int n, int m, const float* xyz1, const float* xyz2, float* temp, float* ws, float* partials,
+                       float* cost, float* grad2_acc, float scale, hpStream_t stream, hpStream_t after);
 int hp_emd_backward(int b, int n, int m, const float* xyz1, const float* xyz2, const float* ws, float* grad2,
                     hpStream_t stream);
 

@@ -436,6 +436,43 @@ def test_emd_training_call_full_size_vs_oracle(oracle_lib, B):
     _assert_grad_close(g2[pick], o2_lit, "grad2 (training gradient) vs oracle(contract=0, literal source)")
 
 
+@pytest.mark.parametrize("b,n,m,side", [(3, 200, 200, True), (2, 1024, 1024, False), (64, 512, 512, True)])
+def test_emd_forward_acc_adds_onto_a_running_gradient(b, n, m, side):
+    """hp_emd_forward_acc (the engine's call): grad2_acc += scale * grad2 inside the gradient sweep, ordered behind the stream
+    that wrote the running gradient — equals hp_emd_forward followed by the axpy it replaces (to the rounding of one fma)."""
+    from hyperpocket_amd._lib import call, current_stream, load_library
+    import ctypes
+    a, c = _clouds(7 * b + n, b, n, m)
+    cost0, _, g2 = _emd_forward(a, c, False, True)
+    A, C = _dev(a), _dev(c)
+    lib = load_library()
+    lib.hp_emd_partials_floats.restype = ctypes.c_long
+    f32 = dict(dtype=torch.float32, device="cuda")
+    temp = torch.empty((b, 2 * (n + m)), **f32)
+    ws = torch.empty((max(1, lib.hp_approxmatch_workspace_floats(b, n, m)),), **f32)
+    part = torch.empty((max(1, lib.hp_emd_partials_floats(b, n, m)),), **f32)
+    cost = torch.empty((b,), **f32)
+    scale = 0.05 / m
+    s2 = torch.cuda.Stream() if side else None
+    cur = torch.cuda.current_stream()
+    if side:
+        s2.wait_stream(cur)
+        with torch.cuda.stream(s2):
+            torch.cuda._sleep(2_000_000)          # the running gradient lands late on the other stream
+            acc = torch.randn(b, m, 3, **f32)
+            base = acc.clone()
+    else:
+        acc = torch.randn(b, m, 3, **f32)
+        base = acc.clone()
+    call("hp_emd_forward_acc", b, n, m, A, C, temp, ws, part, cost, acc, float(scale), current_stream(A.device),
+         ctypes.c_void_p(s2.cuda_stream if side else 0))
+    torch.cuda.synchronize()
+    assert torch.equal(cost, cost0)
+    want = base.double() + scale * g2.double()
+    err = (acc.double() - want).abs().max().item()
+    assert err <= 1e-6 * max(1.0, want.abs().max().item()), err
+
+
 # ----------------------------------------------------------------------------- the reference's exact launcher prototypes
 def _exact_approxmatch(a, c):
     """hp_approxmatch(b,n,m,xyz1,xyz2,match,temp,stream) — structural_loss.cpp:11's argument list, nothing else."""
