@@ -14,11 +14,14 @@
 // Scales (f16 has 5 exponent bits; the split needs |a 2^e| in the normal range, and hi must not overflow):
 //   weights      per output channel (= per row of W): e_w[n] = 14 - exponent(max_k |W[n,k]|), formed with the split itself by
 //                conv_split_prep_kernel once per forward (the weights change only in the optimiser step);
-//   activations  per tensor: the layer that WRITES h_l also forms max|h_l| (post-ReLU values are >= 0, so an unsigned integer
-//                atomicMax on the float bits is an exact, order-independent max — run-to-run identical); the layer that READS
-//                h_l derives e_x = 14 - exponent(max) from it.  Elements below 2^-28 of the tensor's max lose relative
-//                precision in `lo` (f16 subnormals), i.e. the absolute error floor is 2^-39 of the max — far below the
-//                2^-24-of-the-largest-term rounding of any fp32 dot product.
+//   activations  per 128-row tile (the rows one workgroup of the NEXT layer contracts): the layer that WRITES h_l also forms
+//                max|h_l| over each tile (post-ReLU values are >= 0, so an unsigned integer atomicMax on the float bits —
+//                one per workgroup, the tile's column workgroups meet in one word — is an exact, order-independent max:
+//                run-to-run identical); the layer that READS the tile derives e_x = 14 - exponent(max) from it.  Elements
+//                below 2^-28 of their tile's max lose relative precision in `lo` (f16 subnormals), i.e. the absolute error
+//                floor is 2^-39 of the largest activation among the tile's 128 points — far below the
+//                2^-24-of-the-largest-term rounding of any fp32 dot product; an outlier point costs precision only to the
+//                127 points that share its tile.
 //   The accumulator is unscaled by the exact factor 2^-(e_x + e_w[n]) before bias / ReLU.
 //
 // Kernel: 128 x 128 output tile per 4-wave workgroup (64 x 64 per wave), 32-deep k-tiles; the activation tile is loaded
@@ -62,7 +65,8 @@ struct PrepParams {
     _Float16* hi;             // split area of encoder 0
     _Float16* lo;
     int* wexp;
-    unsigned* amax;
+    unsigned* amax;           // 4 * tiles_pad words to clear (the per-tile maxima of layers 1..4)
+    long n_amax;
     long sArea;               // distance (floats) between the two encoders' split areas
 };
 constexpr int kRows[5] = {0, 128, 384, 896, 1408};                 // first row of layer 2..5 in wexp
@@ -72,7 +76,7 @@ constexpr int kK[4] = {64, 128, 256, 512};
 __global__ __launch_bounds__(256) void conv_split_prep_kernel(const PrepParams p) {
     const int z = blockIdx.y, lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (blockIdx.x == 0 && threadIdx.x < 8) p.amax[z * p.sArea + threadIdx.x] = 0u;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.n_amax; i += (long)gridDim.x * 256) p.amax[z * p.sArea + i] = 0u;
     int l = 0;
     while (l < 3 && row >= kRows[l + 1]) ++l;
     const int n = row - kRows[l], K = kK[l];
@@ -121,19 +125,21 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x,
         w2[u] = W[(c4 + u) * 3 + 2];
         bb[u] = b[c4 + u];
     }
-    float m = 0.f;
-    // 64 rows per block pass: 4 rows per thread with their coordinate loads in flight together
-    for (long base = (long)blockIdx.x * 64 + (threadIdx.x >> 4); base < R; base += (long)gridDim.x * 64) {
-        float xv[4][3];
+    // one 128-row tile per block pass (8 rows per thread, their coordinate loads in flight together): the block owns the
+    // tile's maximum — a plain store
+    for (long tile = blockIdx.x; tile * 128 < R; tile += gridDim.x) {
+        const long base = tile * 128 + (threadIdx.x >> 4);
+        float xv[8][3];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 8; ++q) {
             const long row = min(base + 16 * q, R - 1);
             xv[q][0] = x[row * 3];
             xv[q][1] = x[row * 3 + 1];
             xv[q][2] = x[row * 3 + 2];
         }
+        float m = 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 8; ++q) {
             const long row = base + 16 * q;
             f32x4 o;
 #pragma unroll
@@ -146,13 +152,11 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x,
                 *reinterpret_cast<f32x4*>(h + row * 64 + c4) = o;
             }
         }
-    }
-    m = hp::wave_max(m);
-    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        m = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
-        atomicMax(amax + z * sAz, __float_as_uint(m));
+        m = hp::wave_max(m);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) amax[z * sAz + tile] = __float_as_uint(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])));
     }
 }
 
@@ -163,8 +167,8 @@ struct CsParams {
     const _Float16* Whi;       // (N, K) split weights of this layer, encoder 0
     const _Float16* Wlo;
     const int* wexp;           // (N) weight exponents
-    const unsigned* amax_in;   // max of X (float bits)
-    unsigned* amax_out;        // max of C (NULL: not formed)
+    const unsigned* amax_in;   // max of X per 128-row tile (float bits)
+    unsigned* amax_out;        // max of C per 128-row tile (NULL: not formed)
     long sArea;                // distance (floats) between the encoders' split areas
     const float* bias;
     long sBiasz;
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(256, 3) void conv_split_kernel(const CsParams p) {
     const _Float16* Whi = p.Whi + 2 * z * p.sArea;
     const _Float16* Wlo = p.Wlo + 2 * z * p.sArea;
 
-    const int ex = kTarget - frexp_exp(p.amax_in[z * p.sArea]);
+    const int ex = kTarget - frexp_exp(p.amax_in[z * p.sArea + tile_m]);
     const float sx = pow2f(ex);
 
     const float* pa[4];
@@ -373,21 +377,24 @@ __global__ __launch_bounds__(256, 3) void conv_split_kernel(const CsParams p) {
         __syncthreads();
         if (tid == 0) {
             m = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
-            atomicMax(p.amax_out + z * p.sArea, __float_as_uint(m));
+            atomicMax(p.amax_out + z * p.sArea + tile_m, __float_as_uint(m));
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // stand-alone form (hp_gemm_f16x2_*): any fp32 X (M, K) and W (N, K)
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long count, unsigned* __restrict__ amax) {
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long M, int K, unsigned* __restrict__ amax) {
     __shared__ float smax[4];
+    const long r0 = (long)blockIdx.x * 128;
+    const long count = (min(r0 + 128, M) - r0) * K;
+    const float* p = x + r0 * K;
     float m = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    for (long i = threadIdx.x; i < count; i += 256) m = fmaxf(m, fabsf(p[i]));
     m = hp::wave_max(m);
     if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(amax, __float_as_uint(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]))));
+    if (threadIdx.x == 0) amax[blockIdx.x] = __float_as_uint(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])));
 }
 
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ W, int N, int K, _Float16* __restrict__ hi,
@@ -427,7 +434,7 @@ bool g_enabled = [] {
 
 }  // namespace
 
-long hp_conv_split_area_floats() { return HP_CS_AREA_FLOATS; }
+long hp_conv_split_area_floats(long R) { return HP_CS_AMAX_OFF + 4 * hp_conv_split_tiles_pad(R); }
 bool hp_conv_split_enabled() { return g_enabled; }
 HP_API int hp_conv_split_set(int on) {
     const int was = g_enabled;
@@ -435,13 +442,14 @@ HP_API int hp_conv_split_set(int on) {
     return was;
 }
 
-int hp_conv_split_prep(int n, const float* const* W0, const float* const* W1, float* area0, long sArea, hipStream_t stream) {
+int hp_conv_split_prep(int n, const float* const* W0, const float* const* W1, float* area0, long sArea, long R, hipStream_t stream) {
     PrepParams p{};
     for (int l = 0; l < 4; ++l) {
         p.W[l] = W0[l];
         p.sWz[l] = n > 1 ? (long)(W1[l] - W0[l]) : 0;
     }
-    p.amax = reinterpret_cast<unsigned*>(area0);
+    p.amax = reinterpret_cast<unsigned*>(area0 + HP_CS_AMAX_OFF);
+    p.n_amax = 4 * hp_conv_split_tiles_pad(R);
     p.wexp = reinterpret_cast<int*>(area0 + HP_CS_WEXP_OFF);
     p.hi = reinterpret_cast<_Float16*>(area0 + HP_CS_HI_OFF);
     p.lo = reinterpret_cast<_Float16*>(area0 + HP_CS_LO_OFF);
@@ -452,9 +460,9 @@ int hp_conv_split_prep(int n, const float* const* W0, const float* const* W1, fl
 
 int hp_conv_split_layer1(int n, const float* x, long sXz, const float* W, long sWz, const float* b, long sBz, float* h1, long sHz,
                          float* area0, long sArea, long R, hipStream_t stream) {
-    const long blocks = (R + 63) / 64;
-    hipLaunchKernelGGL(conv1_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024), n), dim3(256), 0, stream, x, sXz, W, sWz, b,
-                       sBz, h1, sHz, reinterpret_cast<unsigned*>(area0) + 1, sArea, R);
+    const long blocks = (R + 127) / 128;
+    hipLaunchKernelGGL(conv1_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048), n), dim3(256), 0, stream, x, sXz, W, sWz, b,
+                       sBz, h1, sHz, reinterpret_cast<unsigned*>(area0 + HP_CS_AMAX_OFF), sArea, R);
     HP_RETURN_LAST_ERROR();
 }
 
@@ -467,8 +475,9 @@ int hp_conv_split_layer(int l, int n, const float* X, long sXz, const float* bia
     p.Whi = reinterpret_cast<const _Float16*>(area0 + HP_CS_HI_OFF) + kWOff[l - 2];
     p.Wlo = reinterpret_cast<const _Float16*>(area0 + HP_CS_LO_OFF) + kWOff[l - 2];
     p.wexp = reinterpret_cast<const int*>(area0 + HP_CS_WEXP_OFF) + kRows[l - 2];
-    p.amax_in = reinterpret_cast<const unsigned*>(area0) + (l - 1);
-    p.amax_out = (relu && !colmax) ? reinterpret_cast<unsigned*>(area0) + l : nullptr;
+    const long tp = hp_conv_split_tiles_pad(M);
+    p.amax_in = reinterpret_cast<const unsigned*>(area0 + HP_CS_AMAX_OFF) + (l - 2) * tp;
+    p.amax_out = (relu && !colmax) ? reinterpret_cast<unsigned*>(area0 + HP_CS_AMAX_OFF) + (l - 1) * tp : nullptr;
     p.sArea = sArea;
     p.bias = bias; p.sBiasz = sBiasz;
     p.C = C; p.sCz = sCz;
@@ -485,31 +494,29 @@ int hp_conv_split_layer(int l, int n, const float* X, long sXz, const float* bia
 }
 
 // ---- the split-f16 GEMM as a stand-alone primitive (bench.py's roofline leg, tests): C = act(X W^T + b), X (M, K), W (N, K)
-// fp32 of either sign; N % 128 == 0, K % 32 == 0, K <= 512.  ws: hp_gemm_f16x2_workspace_floats(N, K) floats.
-// prepare: max|X| and the split of W (what the producing layer's epilogue and conv_split_prep_kernel do inside the stack);
+// fp32 of either sign; N % 128 == 0, K % 32 == 0, K <= 512.  ws: hp_gemm_f16x2_workspace_floats(M, N, K) floats.
+// prepare: max|X| per 128-row tile and the split of W (what the producing layer's epilogue and conv_split_prep_kernel do inside the stack);
 // run: the conv_split_kernel launch alone.
-HP_API long hp_gemm_f16x2_workspace_floats(int N, int K) { return 8L + N + (long)N * K; }
+HP_API long hp_gemm_f16x2_workspace_floats(long M, int N, int K) { return hp_conv_split_tiles_pad(M) + N + (long)N * K; }
 
 HP_API int hp_gemm_f16x2_prepare(long M, int N, int K, const float* X, const float* W, float* ws, hipStream_t stream) {
     HP_CHECK_ARG(M > 0 && N > 0 && K > 0 && N % BN == 0 && K % BK == 0 && K <= 512 && X && W && ws);
-    if (hipMemsetAsync(ws, 0, 32, stream) != hipSuccess) return (int)hipGetLastError();
-    const long count = M * K;
-    const long blocks = (count + 256 * 16 - 1) / (256 * 16);
-    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, stream, X, count,
-                       reinterpret_cast<unsigned*>(ws));
-    hipLaunchKernelGGL(split_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, W, N, K, reinterpret_cast<_Float16*>(ws + 8 + N),
-                       reinterpret_cast<_Float16*>(ws + 8 + N) + (long)N * K, reinterpret_cast<int*>(ws + 8));
+    const long tp = hp_conv_split_tiles_pad(M);
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)((M + 127) / 128)), dim3(256), 0, stream, X, M, K, reinterpret_cast<unsigned*>(ws));
+    hipLaunchKernelGGL(split_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, W, N, K, reinterpret_cast<_Float16*>(ws + tp + N),
+                       reinterpret_cast<_Float16*>(ws + tp + N) + (long)N * K, reinterpret_cast<int*>(ws + tp));
     HP_RETURN_LAST_ERROR();
 }
 
 HP_API int hp_gemm_f16x2_run(long M, int N, int K, const float* X, const float* bias, float* C, int relu, const float* ws,
                              hipStream_t stream) {
     HP_CHECK_ARG(M > 0 && M < (1L << 31) && N > 0 && K > 0 && N % BN == 0 && K % BK == 0 && K <= 512 && X && bias && C && ws);
+    const long tp = hp_conv_split_tiles_pad(M);
     CsParams p{};
     p.X = X;
-    p.Whi = reinterpret_cast<const _Float16*>(ws + 8 + N);
+    p.Whi = reinterpret_cast<const _Float16*>(ws + tp + N);
     p.Wlo = p.Whi + (long)N * K;
-    p.wexp = reinterpret_cast<const int*>(ws + 8);
+    p.wexp = reinterpret_cast<const int*>(ws + tp);
     p.amax_in = reinterpret_cast<const unsigned*>(ws);
     p.bias = bias;
     p.C = C;

@@ -3,18 +3,19 @@
 #include <hip/hip_runtime.h>
 
 // The "split area" of one encoder lives behind the activations in its forward workspace (model.hip: enc_fwd_ws):
-//   [0, 8)                      max|h_l| of layers 1..4 as float bits (slot l)
-//   [HP_CS_WEXP_OFF, +1408)     weight exponents e_w of layers 2..5 (128 + 256 + 512 + 512 rows)
+//   [0, 1408)                   weight exponents e_w of layers 2..5 (128 + 256 + 512 + 512 rows)
 //   [HP_CS_HI_OFF, ...)         f16 hi pieces of W2..W5 (434176 halfs), then the lo pieces
-#define HP_CS_WEXP_OFF 8L
-#define HP_CS_HI_OFF (8L + 1408L)
+//   [HP_CS_AMAX_OFF, ...)       max|h_l| per 128-row tile, layers 1..4, as float bits: 4 arrays of hp_conv_split_tiles_pad(R)
+#define HP_CS_WEXP_OFF 0L
+#define HP_CS_HI_OFF 1408L
 #define HP_CS_LO_OFF (HP_CS_HI_OFF + 434176L / 2)
-#define HP_CS_AREA_FLOATS (HP_CS_LO_OFF + 434176L / 2)
+#define HP_CS_AMAX_OFF (HP_CS_LO_OFF + 434176L / 2)
 
-long hp_conv_split_area_floats();
+inline long hp_conv_split_tiles_pad(long R) { return ((R + 127) / 128 + 3) / 4 * 4; }
+long hp_conv_split_area_floats(long R);   // R = B * Np rows
 bool hp_conv_split_enabled();
 // W0 / W1: conv_w[1..4] of the first / second encoder (W1 ignored when n = 1); sArea: distance in floats between the areas
-int hp_conv_split_prep(int n, const float* const* W0, const float* const* W1, float* area0, long sArea, hipStream_t stream);
+int hp_conv_split_prep(int n, const float* const* W0, const float* const* W1, float* area0, long sArea, long R, hipStream_t stream);
 int hp_conv_split_layer1(int n, const float* x, long sXz, const float* W, long sWz, const float* b, long sBz, float* h1, long sHz,
                          float* area0, long sArea, long R, hipStream_t stream);
 int hp_conv_split_layer(int l, int n, const float* X, long sXz, const float* bias, long sBiasz, float* C, long sCz, float* area0,

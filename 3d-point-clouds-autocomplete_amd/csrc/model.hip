@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void vae_head_bwd_kernel(long n, const float* 
 }
 
 // activations h1..h5 of every point, then the split area of conv_split.hip (f16 weight pieces, exponents, activation maxima)
-long enc_fwd_ws(long B, long Np) { return B * Np * (64 + 128 + 256 + 512 + 512) + HP_CS_AREA_FLOATS; }
+long enc_fwd_ws(long B, long Np) { return B * Np * (64 + 128 + 256 + 512 + 512) + hp_conv_split_area_floats(B * Np); }
 long enc_bwd_ws(long B, long out) {
     const long Rc = B * 512;
     return Rc * 4 + Rc * (64 + 128 + 256 + 512) * 2 + B * (2 * out + 4 * 512) + kSplitWs + 64 + (B * (5 * 512 + 4) + 16);
@@ -617,7 +617,7 @@ int encoder_forward_impl(int B, int Np, int out_size, int n, const HpEncoderIO* 
     if (split) {
         const float* W0[4] = {e0.w->conv_w[1], e0.w->conv_w[2], e0.w->conv_w[3], e0.w->conv_w[4]};
         const float* W1[4] = {e1.w->conv_w[1], e1.w->conv_w[2], e1.w->conv_w[3], e1.w->conv_w[4]};
-        TRY(hp_conv_split_prep(n, W0, W1, area, sWs, stream));
+        TRY(hp_conv_split_prep(n, W0, W1, area, sWs, R, stream));
         TRY(hp_conv_split_layer1(n, e0.x, dz(e0.x, e1.x), e0.w->conv_w[0], dz(e0.w->conv_w[0], e1.w->conv_w[0]), e0.w->conv_b[0],
                                  dz(e0.w->conv_b[0], e1.w->conv_b[0]), h[1], sWs, area, sWs, R, stream));
         for (int l = 2; l <= 4; ++l)

@@ -487,7 +487,7 @@ class GemmF16x2:
         if W.shape[1] != self.K or bias.numel() != self.N:
             raise HipExtensionError("GemmF16x2: X (M,K), W (N,K), bias (N)")
         self.X, self.W, self.bias, self.relu = X, W, bias, int(relu)
-        self.ws = torch.empty((_long_fn("hp_gemm_f16x2_workspace_floats", self.N, self.K),), dtype=torch.float32, device=X.device)
+        self.ws = torch.empty((_long_fn("hp_gemm_f16x2_workspace_floats", c_long(self.M), self.N, self.K),), dtype=torch.float32, device=X.device)
         self.C = out if out is not None else torch.empty((self.M, self.N), dtype=torch.float32, device=X.device)
         call("hp_gemm_f16x2_prepare", c_long(self.M), self.N, self.K, X, W, self.ws, current_stream(X.device))
 

@@ -262,10 +262,10 @@ int hp_encoder_backward_set_fused(int on);
  * through the fp32 MFMA GEMMs instead (also: environment HP_CONV_SPLIT=0).  Returns the previous setting. */
 int hp_conv_split_set(int on);
 /* The same split-f16 GEMM as a stand-alone primitive: C = act(X W^T + b), X (M,K) and W (N,K) fp32 of either sign, row-major;
- * N % 128 == 0, K % 32 == 0, K <= 512.  prepare forms max|X| and the f16 pieces / per-row exponents of W in ws
- * (hp_gemm_f16x2_workspace_floats(N, K) floats — inside the encoder stack the producing layer's epilogue and one prep launch
+ * N % 128 == 0, K % 32 == 0, K <= 512.  prepare forms max|X| per 128-row tile and the f16 pieces / per-row exponents of W in ws
+ * (hp_gemm_f16x2_workspace_floats(M, N, K) floats — inside the encoder stack the producing layer's epilogue and one prep launch
  * per forward do this); run is the GEMM launch alone (bench.py times it).  relu != 0: max(., 0). */
-long hp_gemm_f16x2_workspace_floats(int N, int K);
+long hp_gemm_f16x2_workspace_floats(long M, int N, int K);
 int hp_gemm_f16x2_prepare(long M, int N, int K, const float* X, const float* W, float* ws, hpStream_t stream);
 int hp_gemm_f16x2_run(long M, int N, int K, const float* X, const float* bias, float* C, int relu, const float* ws, hpStream_t stream);
 

@@ -274,6 +274,32 @@ def test_conv_stack_split_f16_is_as_close_to_fp64_as_the_fp32_chain(B, Np, xscal
         assert max_s <= 2e-6, msg
 
 
+def test_conv_stack_split_outlier_point_costs_only_its_tile():
+    """The activation scale of the split-f16 conv layers is per 128-row tile: a point whose activations are 1e5 x everybody
+    else's must not cost the points of OTHER tiles any precision (per-row error relative to the row's own scale stays at the
+    fp32 chain's level)."""
+    from hyperpocket_amd.model.encoder import Encoder
+    from hyperpocket_amd.core.setup import weights_init
+    torch.manual_seed(23)
+    enc = Encoder({"output_size": 128, "use_bias": True, "relu_slope": 0.2}, is_vae=False).apply(weights_init).cuda()
+    params = [p.detach().reshape(p.shape[0], -1).contiguous() if p.dim() == 3 else p.detach().contiguous() for p in enc._params()]
+    B, Np = 2, 1024
+    x = (torch.rand(B, Np, 3, device="cuda") - 0.5).contiguous()
+    x[0, 5] *= 1e5                                          # row 5 of tile 0
+    worst = {}
+    for split in (True, False):
+        hs, _, _ = _conv_stack_from_workspace(B, Np, x, params, split)
+        prev = x.view(B * Np, 3)
+        w = 0.0
+        for l in range(4):
+            want = torch.relu(prev.double() @ params[l].double().t() + params[5 + l].double())
+            rel = (hs[l].double() - want).abs() / want.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+            w = max(w, rel[128:].max().item())              # every row outside the outlier's tile
+            prev = hs[l]
+        worst[split] = w
+    assert worst[True] <= 2e-6 and worst[True] <= 3 * worst[False] + 1e-7, worst
+
+
 def test_encoder_backward_gather_equals_recompute():
     """The two sources of the critical rows' activations (copied out of the forward's workspace / recomputed from the
     gathered coordinates) give bit-identical parameter gradients."""

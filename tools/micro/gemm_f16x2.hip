@@ -629,6 +629,133 @@ __global__ __launch_bounds__(256, MINB) void split_gemm4(const float* __restrict
         }
 }
 
+// v5: v3 (two-barrier loop, swizzled LDS, 128 x 128 tile) with a 64-deep k-tile: twice the bytes in flight per workgroup and
+// half the barriers per MFMA.  128-byte LDS rows, 16-byte chunk c of row r at chunk c ^ ((r >> 1) & 7).
+template <int MINB>
+__global__ __launch_bounds__(256, MINB) void split_gemm5(const float* __restrict__ X, const _Float16* __restrict__ Whi,
+                                                        const _Float16* __restrict__ Wlo, const float* __restrict__ bias,
+                                                        float* __restrict__ C, int M, int N, int K, float sx, float unscale,
+                                                        int store) {
+    constexpr int BM = 128, BNN = 128, BKT = 64, ROW = BKT;
+    __shared__ __attribute__((aligned(16))) _Float16 lds[2 * BM * ROW + 2 * BNN * ROW];   // 64 KB
+    _Float16* Ah = lds;
+    _Float16* Al = lds + BM * ROW;
+    _Float16* Bh = lds + 2 * BM * ROW;
+    _Float16* Bl = Bh + BNN * ROW;
+    const int tiles_n = N / BNN;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    }
+    const int tile_n = bid % tiles_n, tile_m = bid / tiles_n;
+    const int row0 = tile_m * BM, col0 = tile_n * BNN;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int wm = w >> 1, wn = w & 1;
+    auto swz = [](int row, int chunk) { return chunk ^ ((row >> 1) & 7); };
+    const float* pa[8];
+    int a_off[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int idx = tid + e * 256, row = idx >> 4, kq = idx & 15;   // 16 threads per row, 4 k each
+        pa[e] = X + (long)(row0 + row) * K + 4 * kq;
+        a_off[e] = row * ROW + (swz(row, kq >> 1) << 3) + 4 * (kq & 1);
+    }
+    const _Float16* pbh[4];
+    const _Float16* pbl[4];
+    int b_off[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int idx = tid + e * 256, row = idx >> 3, c = idx & 7;
+        pbh[e] = Whi + (long)(col0 + row) * K + 8 * c;
+        pbl[e] = Wlo + (long)(col0 + row) * K + 8 * c;
+        b_off[e] = row * ROW + (swz(row, c) << 3);
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    f32x4 ra[8];
+    u32x4 rbh[4], rbl[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ra[e] = *reinterpret_cast<const f32x4*>(pa[e] + k0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            rbh[e] = *reinterpret_cast<const u32x4*>(pbh[e] + k0);
+            rbl[e] = *reinterpret_cast<const u32x4*>(pbl[e] + k0);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            f16x4 hi, lo;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float xs = ra[e][u] * sx;
+                const _Float16 hh = (_Float16)xs;
+                hi[u] = hh;
+                lo[u] = (_Float16)(xs - (float)hh);
+            }
+            *reinterpret_cast<f16x4*>(&Ah[a_off[e]]) = hi;
+            *reinterpret_cast<f16x4*>(&Al[a_off[e]]) = lo;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            *reinterpret_cast<u32x4*>(&Bh[b_off[e]]) = rbh[e];
+            *reinterpret_cast<u32x4*>(&Bl[b_off[e]]) = rbl[e];
+        }
+    };
+    auto compute = [&]() {
+#pragma unroll
+        for (int t = 0; t < BKT / 16; ++t) {
+            f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ar = wm * 64 + i * 32 + r, br = wn * 64 + i * 32 + r;
+                const int oa = ar * ROW + (swz(ar, 2 * t + h) << 3), ob = br * ROW + (swz(br, 2 * t + h) << 3);
+                ah[i] = *reinterpret_cast<const f16x8*>(&Ah[oa]);
+                al[i] = *reinterpret_cast<const f16x8*>(&Al[oa]);
+                bh[i] = *reinterpret_cast<const f16x8*>(&Bh[ob]);
+                bl[i] = *reinterpret_cast<const f16x8*>(&Bl[ob]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += BKT) {
+        stage();
+        __syncthreads();
+        if (k0 + BKT < K) fetch(k0 + BKT);
+        compute();
+        __syncthreads();
+    }
+    if (!(store & 1)) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = col0 + wn * 64 + j * 32 + r;
+            const float bv = bias[col];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = row0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                C[(long)row * N + col] = fmaxf(acc[i][j][e] * unscale + bv, 0.f);
+            }
+        }
+}
+
 static double urand() { return (rand() + 0.5) / (RAND_MAX + 1.0); }
 static double nrand() { return sqrt(-2.0 * log(urand())) * cos(6.283185307179586 * urand()); }
 
@@ -679,7 +806,9 @@ static void run(const char* name, int M, int N, int K, float xmag, int reps) {
     CK(hipEventCreate(&e1));
     for (int store : {1, 0}) {
         auto launch = [&]() {
-            if (VER == 4)
+            if (VER == 5)
+                hipLaunchKernelGGL((split_gemm5<MINB>), dim3(grid), dim3(256), 0, 0, dX, dWh, dWl, db, dC, M, N, K, sx, unscale, store);
+            else if (VER == 4)
                 hipLaunchKernelGGL((split_gemm4<MINB>), dim3(grid), dim3(256), 0, 0, dX, dWh, dWl, db, dC, M, N, K, sx, unscale, store);
             else if (VER == 3)
                 hipLaunchKernelGGL((split_gemm3<MINB, TM>), dim3((M / 128) * (N / (64 * TM))), dim3(256), 0, 0, dX, dWh, dWl, db, dC, M, N, K, sx, unscale, store);
@@ -734,9 +863,8 @@ int main() {
     srand(2020);
     const int M = 131072;   // both encoders of a B=64 step: 2 x 64 x 1024 points
     run<false, 3, 2, false, 3>("conv5", M, 512, 512, 1.f, 20);
-    run<false, 3, 2, false, 4>("conv5", M, 512, 512, 1.f, 20);
-    run<false, 4, 2, false, 4>("conv5", M, 512, 512, 1.f, 20);
-    run<false, 3, 2, false, 4>("conv4", M, 512, 256, 1.f, 20);
-    run<false, 3, 2, false, 4>("conv3", M, 256, 128, 1.f, 20);
+    run<false, 2, 2, false, 5>("conv5", M, 512, 512, 1.f, 20);
+    run<false, 2, 2, false, 5>("conv4", M, 512, 256, 1.f, 20);
+    run<false, 2, 2, false, 5>("conv3", M, 256, 128, 1.f, 20);
     return 0;
 }
