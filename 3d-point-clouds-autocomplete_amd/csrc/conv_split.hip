@@ -26,7 +26,7 @@
 //
 // Kernel: 128 x 128 output tile per 4-wave workgroup (64 x 64 per wave), 32-deep k-tiles; the activation tile is loaded
 // as fp32 (16-byte loads), split in registers and stored as two f16 LDS images, the weight tile is copied from the pre-split
-// f16 arrays; swizzled 64-byte LDS rows keep the stage writes and the ds_read_b128 fragment reads conflict-free.
+// f16 array (hi and lo pieces interleaved per k-tile: full 128-byte lines); swizzled 64-byte LDS rows keep the stage writes and the ds_read_b128 fragment reads conflict-free.
 // tools/micro/gemm_f16x2.hip holds the variants measured against this one (cross-tile software pipeline with a raw barrier,
 // double-buffered LDS, 256 x 128 and 128 x 256 tiles, the 16x16x32 MFMA shape): all within +-6 % — the kernel sits at the
 // ~0.9 PFLOP/s (executed f16) that cdna_hip_programming.md quotes as the ceiling of two-barrier 128^2 structures, at a clock
@@ -62,8 +62,7 @@ __device__ __forceinline__ float pow2f(int e) {   // 2^e, e clamped into the nor
 struct PrepParams {
     const float* W[4];        // conv_w[1..4] of encoder 0
     long sWz[4];              // distance to encoder 1's tensor
-    _Float16* hi;             // split area of encoder 0
-    _Float16* lo;
+    _Float16* hl;             // split area of encoder 0: interleaved pieces
     int* wexp;
     unsigned* amax;           // 4 * tiles_pad words to clear (the per-tile maxima of layers 1..4)
     long n_amax;
@@ -93,16 +92,17 @@ __global__ __launch_bounds__(256) void conv_split_prep_kernel(const PrepParams p
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     const int e = kTarget - frexp_exp(__float_as_uint(m));
     const float s = pow2f(e);
-    _Float16* hi = p.hi + 2 * z * p.sArea + kWOff[l] + (long)n * K;
-    _Float16* lo = p.lo + 2 * z * p.sArea + kWOff[l] + (long)n * K;
+    // pieces interleaved per 32-deep k-tile: row n = [hi(k 0..31) | lo(k 0..31) | hi(k 32..63) | ...]: one full 128-byte line
+    // per (row, k-tile) for the GEMM's weight-tile loads (two half-used lines with separate hi / lo arrays: measured -6 % on conv5)
+    _Float16* hl = p.hl + 2 * z * p.sArea + 2 * kWOff[l] + (long)n * 2 * K;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int k = lane + 64 * u;
         if (k < K) {
             const float xs = v[u] * s;
             const _Float16 hh = (_Float16)xs;
-            hi[k] = hh;
-            lo[k] = (_Float16)(xs - (float)hh);
+            hl[(k >> 5) * 64 + (k & 31)] = hh;
+            hl[(k >> 5) * 64 + 32 + (k & 31)] = (_Float16)(xs - (float)hh);
         }
     }
     if (lane == 0) p.wexp[z * p.sArea + row] = e;
@@ -164,8 +164,7 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x,
 struct CsParams {
     const float* X;            // (M, K) row-major activations of encoder 0
     long sXz;
-    const _Float16* Whi;       // (N, K) split weights of this layer, encoder 0
-    const _Float16* Wlo;
+    const _Float16* Whl;       // (N, 2K) split weights of this layer, encoder 0: per row and 32-deep k-tile [hi 32 | lo 32]
     const int* wexp;           // (N) weight exponents
     const unsigned* amax_in;   // max of X per 128-row tile (float bits)
     unsigned* amax_out;        // max of C per 128-row tile (NULL: not formed)
@@ -201,8 +200,7 @@ __global__ __launch_bounds__(256, 3) void conv_split_kernel(const CsParams p) {
     const int wm = w >> 1, wn = w & 1;
     const int K = p.K, M = p.M;
     const float* X = p.X + z * p.sXz;
-    const _Float16* Whi = p.Whi + 2 * z * p.sArea;
-    const _Float16* Wlo = p.Wlo + 2 * z * p.sArea;
+    const _Float16* Whl = p.Whl + 2 * z * p.sArea;
 
     const int ex = kTarget - frexp_exp(p.amax_in[z * p.sArea + tile_m]);
     const float sx = pow2f(ex);
@@ -215,15 +213,14 @@ __global__ __launch_bounds__(256, 3) void conv_split_kernel(const CsParams p) {
         pa[e] = X + (long)min(row0 + row, M - 1) * K + 4 * kq;
         a_off[e] = row * ROW + (((kq >> 1) ^ ((row >> 2) & 3)) << 3) + 4 * (kq & 1);
     }
-    const _Float16* pbh[2];
-    const _Float16* pbl[2];
-    int b_off[2];
+    // weight tile: 128 rows x [hi 32 | lo 32] = 8 chunks of 16 bytes per row, 4 per thread
+    const _Float16* pb[4];
+    _Float16* bdst[4];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int idx = tid + e * 256, row = idx >> 2, c = idx & 3;
-        pbh[e] = Whi + (long)(col0 + row) * K + 8 * c;
-        pbl[e] = Wlo + (long)(col0 + row) * K + 8 * c;
-        b_off[e] = row * ROW + ((c ^ ((row >> 2) & 3)) << 3);
+    for (int e = 0; e < 4; ++e) {
+        const int idx = tid + e * 256, row = idx >> 3, c = idx & 7;
+        pb[e] = Whl + (long)(col0 + row) * 2 * K + 8 * c;
+        bdst[e] = ((c >> 2) ? Bl : Bh) + row * ROW + (((c & 3) ^ ((row >> 2) & 3)) << 3);
     }
 
     f32x16 acc[2][2];
@@ -235,15 +232,12 @@ __global__ __launch_bounds__(256, 3) void conv_split_kernel(const CsParams p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     f32x4 ra[4];
-    u32x4 rbh[2], rbl[2];
+    u32x4 rb[4];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) ra[e] = *reinterpret_cast<const f32x4*>(pa[e] + k0);
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            rbh[e] = *reinterpret_cast<const u32x4*>(pbh[e] + k0);
-            rbl[e] = *reinterpret_cast<const u32x4*>(pbl[e] + k0);
-        }
+        for (int e = 0; e < 4; ++e) rb[e] = *reinterpret_cast<const u32x4*>(pb[e] + 2 * k0);
     };
     auto stage = [&]() {
 #pragma unroll
@@ -260,10 +254,7 @@ __global__ __launch_bounds__(256, 3) void conv_split_kernel(const CsParams p) {
             *reinterpret_cast<f16x4*>(&Al[a_off[e]]) = lo;
         }
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            *reinterpret_cast<u32x4*>(&Bh[b_off[e]]) = rbh[e];
-            *reinterpret_cast<u32x4*>(&Bl[b_off[e]]) = rbl[e];
-        }
+        for (int e = 0; e < 4; ++e) *reinterpret_cast<u32x4*>(bdst[e]) = rb[e];
     };
     auto compute = [&]() {
 #pragma unroll
@@ -397,8 +388,8 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     if (threadIdx.x == 0) amax[blockIdx.x] = __float_as_uint(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])));
 }
 
-__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ W, int N, int K, _Float16* __restrict__ hi,
-                                                         _Float16* __restrict__ lo, int* __restrict__ wexp) {
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ W, int N, int K, _Float16* __restrict__ hl,
+                                                         int* __restrict__ wexp) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= N) return;
     const float* w = W + (long)row * K;
@@ -414,14 +405,15 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     const int e = kTarget - frexp_exp(__float_as_uint(m));
     const float sc = pow2f(e);
+    _Float16* out = hl + (long)row * 2 * K;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int k = lane + 64 * u;
         if (k < K) {
             const float xs = v[u] * sc;
             const _Float16 hh = (_Float16)xs;
-            hi[(long)row * K + k] = hh;
-            lo[(long)row * K + k] = (_Float16)(xs - (float)hh);
+            out[(k >> 5) * 64 + (k & 31)] = hh;
+            out[(k >> 5) * 64 + 32 + (k & 31)] = (_Float16)(xs - (float)hh);
         }
     }
     if (lane == 0) wexp[row] = e;
@@ -451,8 +443,7 @@ int hp_conv_split_prep(int n, const float* const* W0, const float* const* W1, fl
     p.amax = reinterpret_cast<unsigned*>(area0 + HP_CS_AMAX_OFF);
     p.n_amax = 4 * hp_conv_split_tiles_pad(R);
     p.wexp = reinterpret_cast<int*>(area0 + HP_CS_WEXP_OFF);
-    p.hi = reinterpret_cast<_Float16*>(area0 + HP_CS_HI_OFF);
-    p.lo = reinterpret_cast<_Float16*>(area0 + HP_CS_LO_OFF);
+    p.hl = reinterpret_cast<_Float16*>(area0 + HP_CS_HI_OFF);
     p.sArea = sArea;
     hipLaunchKernelGGL(conv_split_prep_kernel, dim3(kRows[4] / 4, n), dim3(256), 0, stream, p);
     HP_RETURN_LAST_ERROR();
@@ -472,8 +463,7 @@ int hp_conv_split_layer(int l, int n, const float* X, long sXz, const float* bia
     if (l < 2 || l > 5 || M <= 0) return -1;
     CsParams p{};
     p.X = X; p.sXz = sXz;
-    p.Whi = reinterpret_cast<const _Float16*>(area0 + HP_CS_HI_OFF) + kWOff[l - 2];
-    p.Wlo = reinterpret_cast<const _Float16*>(area0 + HP_CS_LO_OFF) + kWOff[l - 2];
+    p.Whl = reinterpret_cast<const _Float16*>(area0 + HP_CS_HI_OFF) + 2 * kWOff[l - 2];
     p.wexp = reinterpret_cast<const int*>(area0 + HP_CS_WEXP_OFF) + kRows[l - 2];
     const long tp = hp_conv_split_tiles_pad(M);
     p.amax_in = reinterpret_cast<const unsigned*>(area0 + HP_CS_AMAX_OFF) + (l - 2) * tp;
@@ -504,7 +494,7 @@ HP_API int hp_gemm_f16x2_prepare(long M, int N, int K, const float* X, const flo
     const long tp = hp_conv_split_tiles_pad(M);
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)((M + 127) / 128)), dim3(256), 0, stream, X, M, K, reinterpret_cast<unsigned*>(ws));
     hipLaunchKernelGGL(split_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, W, N, K, reinterpret_cast<_Float16*>(ws + tp + N),
-                       reinterpret_cast<_Float16*>(ws + tp + N) + (long)N * K, reinterpret_cast<int*>(ws + tp));
+                       reinterpret_cast<int*>(ws + tp));
     HP_RETURN_LAST_ERROR();
 }
 
@@ -514,8 +504,7 @@ HP_API int hp_gemm_f16x2_run(long M, int N, int K, const float* X, const float* 
     const long tp = hp_conv_split_tiles_pad(M);
     CsParams p{};
     p.X = X;
-    p.Whi = reinterpret_cast<const _Float16*>(ws + tp + N);
-    p.Wlo = p.Whi + (long)N * K;
+    p.Whl = reinterpret_cast<const _Float16*>(ws + tp + N);
     p.wexp = reinterpret_cast<const int*>(ws + tp);
     p.amax_in = reinterpret_cast<const unsigned*>(ws);
     p.bias = bias;

@@ -4,7 +4,7 @@
 
 // The "split area" of one encoder lives behind the activations in its forward workspace (model.hip: enc_fwd_ws):
 //   [0, 1408)                   weight exponents e_w of layers 2..5 (128 + 256 + 512 + 512 rows)
-//   [HP_CS_HI_OFF, ...)         f16 hi pieces of W2..W5 (434176 halfs), then the lo pieces
+//   [HP_CS_HI_OFF, ...)         f16 pieces of W2..W5 (2 x 434176 halfs): per row and 32-deep k-tile [hi 32 | lo 32]
 //   [HP_CS_AMAX_OFF, ...)       max|h_l| per 128-row tile, layers 1..4, as float bits: 4 arrays of hp_conv_split_tiles_pad(R)
 #define HP_CS_WEXP_OFF 0L
 #define HP_CS_HI_OFF 1408L

@@ -18,6 +18,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+__device__ unsigned long long* g_prof = nullptr;
 #define CK(x)                                                                     \
     do {                                                                          \
         hipError_t e_ = (x);                                                      \
@@ -364,6 +365,7 @@ __global__ __launch_bounds__(256, MINB) void split_gemm3(const float* __restrict
                                                         const _Float16* __restrict__ Wlo, const float* __restrict__ bias,
                                                         float* __restrict__ C, int M, int N, int K, float sx, float unscale,
                                                         int store) {
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime(), r_entry = __builtin_amdgcn_s_memrealtime();
     constexpr int BM = 128, BNN = 64 * TN, ROW = 32, NB = BNN / 64;   // NB 16-byte chunk passes of the B images per thread
     __shared__ __attribute__((aligned(16))) _Float16 lds[2 * BM * ROW + 2 * BNN * ROW];   // Ah, Al, Bh, Bl
     _Float16* Ah = lds;
@@ -393,12 +395,34 @@ __global__ __launch_bounds__(256, MINB) void split_gemm3(const float* __restrict
     const _Float16* pbh[NB];
     const _Float16* pbl[NB];
     int b_off[NB];
+    const bool inter = store & 64;   // W as [N][K/32][hi 32 | lo 32]: one full 128-byte line per (row, k-tile)
+    long b_kstep = BK;
 #pragma unroll
     for (int e = 0; e < NB; ++e) {
         const int idx = tid + e * 256, row = idx >> 2, c = idx & 3;
         pbh[e] = Whi + (long)(col0 + row) * K + 8 * c;
         pbl[e] = Wlo + (long)(col0 + row) * K + 8 * c;
         b_off[e] = row * ROW + ((c ^ ((row >> 2) & 3)) << 3);
+    }
+    if (inter) {
+        b_kstep = 2 * BK;
+#pragma unroll
+        for (int e = 0; e < NB; ++e) {
+            // 2 * NB chunk passes in all: pass p = e (first half -> "pbh"), e + NB (second half -> "pbl"); 8 lanes per row
+            const int i0 = tid + e * 256, i1 = tid + (e + NB) * 256;
+            const int r0 = i0 >> 3, c0 = i0 & 7, r1 = i1 >> 3, c1 = i1 & 7;
+            pbh[e] = Whi + (long)(col0 + r0) * 2 * K + 8 * c0;
+            pbl[e] = Whi + (long)(col0 + r1) * 2 * K + 8 * c1;
+            // chunk c < 4: hi image, chunk c - 4: lo image (Bl = Bh + BNN * ROW)
+            b_off[e] = (c0 >> 2) * BNN * ROW + r0 * ROW + (((c0 & 3) ^ ((r0 >> 2) & 3)) << 3);
+            // second pass offset kept relative to Bl's base: (c1 >> 2) == 1 -> Bl, else Bh = Bl - BNN * ROW
+        }
+    }
+    int b_off2[NB];
+#pragma unroll
+    for (int e = 0; e < NB; ++e) {
+        const int i1 = tid + (e + NB) * 256, r1 = i1 >> 3, c1 = i1 & 7;
+        b_off2[e] = inter ? ((c1 >> 2) * BNN * ROW + r1 * ROW + (((c1 & 3) ^ ((r1 >> 2) & 3)) << 3)) : (BNN * ROW + b_off[e]);
     }
     int fa[2][2], fb[TN][2];
 #pragma unroll
@@ -429,8 +453,8 @@ __global__ __launch_bounds__(256, MINB) void split_gemm3(const float* __restrict
         for (int e = 0; e < 4; ++e) ra[e] = *reinterpret_cast<const f32x4*>(pa[e] + k0);
 #pragma unroll
         for (int e = 0; e < NB; ++e) {
-            rbh[e] = *reinterpret_cast<const u32x4*>(pbh[e] + k0);
-            rbl[e] = *reinterpret_cast<const u32x4*>(pbl[e] + k0);
+            rbh[e] = *reinterpret_cast<const u32x4*>(pbh[e] + (k0 / BK) * b_kstep);
+            rbl[e] = *reinterpret_cast<const u32x4*>(pbl[e] + (k0 / BK) * b_kstep);
         }
     };
     auto stage = [&]() {
@@ -450,7 +474,7 @@ __global__ __launch_bounds__(256, MINB) void split_gemm3(const float* __restrict
 #pragma unroll
         for (int e = 0; e < NB; ++e) {
             *reinterpret_cast<u32x4*>(&Bh[b_off[e]]) = rbh[e];
-            *reinterpret_cast<u32x4*>(&Bl[b_off[e]]) = rbl[e];
+            *reinterpret_cast<u32x4*>(&Bh[b_off2[e]]) = rbl[e];
         }
     };
     auto compute = [&]() {
@@ -478,12 +502,51 @@ __global__ __launch_bounds__(256, MINB) void split_gemm3(const float* __restrict
         }
     };
     fetch(0);
-    for (int k0 = 0; k0 < K; k0 += BK) {
-        stage();
-        __syncthreads();
-        if (k0 + BK < K) fetch(k0 + BK);
-        compute();
-        __syncthreads();
+    if (store & 16) {   // in-kernel stamps (diagnostic run): where a wave's cycles go
+        unsigned long long acc_t[4] = {0, 0, 0, 0};
+        const unsigned long long tb = __builtin_amdgcn_s_memtime();
+        for (int k0 = 0; k0 < K; k0 += BK) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            stage();
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+            __syncthreads();
+            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+            if (k0 + BK < K) fetch(k0 + BK);
+            compute();
+            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+            __syncthreads();
+            const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+            acc_t[0] += t1 - t0; acc_t[1] += t2 - t1; acc_t[2] += t3 - t2; acc_t[3] += t4 - t3;
+        }
+        const unsigned long long te = __builtin_amdgcn_s_memtime();
+        if (lane == 0 && g_prof) {
+            unsigned long long* o = g_prof + ((long)blockIdx.x * 4 + w) * 8;
+            o[0] = acc_t[0]; o[1] = acc_t[1]; o[2] = acc_t[2]; o[3] = acc_t[3]; o[4] = te - tb; o[5] = tb - t_entry;
+            o[6] = r_entry; o[7] = __builtin_amdgcn_s_memrealtime();
+        }
+        return;
+    }
+    if (store & 32) {   // the same loop with the phases pinned apart (no stamps)
+        for (int k0 = 0; k0 < K; k0 += BK) {
+            __builtin_amdgcn_sched_barrier(0);
+            stage();
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            if (k0 + BK < K) fetch(k0 + BK);
+            compute();
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        for (int k0 = 0; k0 < K; k0 += BK) {
+            stage();
+            __syncthreads();
+            if (k0 + BK < K) fetch(k0 + BK);
+            compute();
+            __syncthreads();
+        }
     }
     if (!(store & 1)) return;
 #pragma unroll
@@ -495,7 +558,9 @@ __global__ __launch_bounds__(256, MINB) void split_gemm3(const float* __restrict
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = row0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                C[(long)row * N + col] = fmaxf(acc[i][j][e] * unscale + bv, 0.f);
+                const float v = fmaxf(acc[i][j][e] * unscale + bv, 0.f);
+                if (store & 128) __builtin_nontemporal_store(v, &C[(long)row * N + col]);
+                else C[(long)row * N + col] = v;
             }
         }
 }
@@ -788,12 +853,20 @@ static void run(const char* name, int M, int N, int K, float xmag, int reps) {
         Wl[i] = (_Float16)(s - (float)hh);
     }
     float *dX, *db, *dC;
-    _Float16 *dWh, *dWl;
+    _Float16 *dWh, *dWl, *dWi;
+    std::vector<_Float16> Wi(2 * W.size());
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) {
+            Wi[(size_t)n * 2 * K + (k / 32) * 64 + (k % 32)] = Wh[(size_t)n * K + k];
+            Wi[(size_t)n * 2 * K + (k / 32) * 64 + 32 + (k % 32)] = Wl[(size_t)n * K + k];
+        }
     CK(hipMalloc(&dX, X.size() * 4));
     CK(hipMalloc(&db, N * 4));
     CK(hipMalloc(&dC, (size_t)M * N * 4));
     CK(hipMalloc(&dWh, W.size() * 2));
     CK(hipMalloc(&dWl, W.size() * 2));
+    CK(hipMalloc(&dWi, W.size() * 4));
+    CK(hipMemcpy(dWi, Wi.data(), W.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dX, X.data(), X.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(db, b.data(), N * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dWh, Wh.data(), W.size() * 2, hipMemcpyHostToDevice));
@@ -804,14 +877,14 @@ static void run(const char* name, int M, int N, int K, float xmag, int reps) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    for (int store : {1, 0}) {
+    for (int store : {1, 65, 193, 64}) {
         auto launch = [&]() {
             if (VER == 5)
                 hipLaunchKernelGGL((split_gemm5<MINB>), dim3(grid), dim3(256), 0, 0, dX, dWh, dWl, db, dC, M, N, K, sx, unscale, store);
             else if (VER == 4)
                 hipLaunchKernelGGL((split_gemm4<MINB>), dim3(grid), dim3(256), 0, 0, dX, dWh, dWl, db, dC, M, N, K, sx, unscale, store);
             else if (VER == 3)
-                hipLaunchKernelGGL((split_gemm3<MINB, TM>), dim3((M / 128) * (N / (64 * TM))), dim3(256), 0, 0, dX, dWh, dWl, db, dC, M, N, K, sx, unscale, store);
+                hipLaunchKernelGGL((split_gemm3<MINB, TM>), dim3((M / 128) * (N / (64 * TM))), dim3(256), 0, 0, dX, (store & 64) ? dWi : dWh, dWl, db, dC, M, N, K, sx, unscale, store);
             else if (VER == 2)
                 hipLaunchKernelGGL((split_gemm2<MINB>), dim3(grid), dim3(256), 0, 0, dX, dWh, dWl, db, dC, M, N, K, sx, unscale, store);
             else
@@ -827,6 +900,36 @@ static void run(const char* name, int M, int N, int K, float xmag, int reps) {
         const double us = ms * 1e3 / reps;
         printf("%-6s v%d M=%d N=%d K=%d sep=%d minb=%d TM=%d DB=%d store=%d: %8.1f us  %7.1f TFLOP/s (fp32-equivalent)\n", name, VER, M, N, K, (int)SEP, MINB, TM, (int)DB,
                store, us, 2.0 * M * N * K / us * 1e-6);
+    }
+    if (VER == 3) {
+        auto launch_store = [&](int st) {
+            hipLaunchKernelGGL((split_gemm3<MINB, TM>), dim3((M / 128) * (N / (64 * TM))), dim3(256), 0, 0, dX, dWh, dWl, db, dC, M, N, K, sx, unscale, st);
+        };
+        unsigned long long* dprof;
+        const size_t np = (size_t)grid * 4 * 8;
+        CK(hipMalloc(&dprof, np * 8));
+        CK(hipMemset(dprof, 0, np * 8));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), &dprof, sizeof(dprof)));
+        for (int i = 0; i < 20; ++i) launch_store(0);
+        launch_store(16);
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> hp(np);
+        CK(hipMemcpy(hp.data(), dprof, np * 8, hipMemcpyDeviceToHost));
+        double sum[6] = {0, 0, 0, 0, 0, 0}, life = 0;
+        unsigned long long rmin = ~0ull, rmax = 0;
+        for (size_t i = 0; i < np; i += 8) {
+            for (int q = 0; q < 6; ++q) sum[q] += hp[i + q];
+            life += (double)(hp[i + 7] - hp[i + 6]);
+            if (hp[i + 6] < rmin) rmin = hp[i + 6];
+            if (hp[i + 7] > rmax) rmax = hp[i + 7];
+        }
+        const double nw = np / 8.0;
+        printf("       stamps (cycles per wave, %d k-tiles): entry->loop %.0f | stage+vmcnt %.0f | barrier1 %.0f | fetch-issue+compute %.0f | barrier2 %.0f | loop total %.0f\n",
+               K / BK, sum[5] / nw, sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[4] / nw);
+        printf("       realtime (100 MHz): wave life %.2f us avg, kernel span %.1f us, waves in flight on average %.0f (= %.2f per SIMD)\n",
+               life / nw / 100.0, (rmax - rmin) / 100.0, life / (double)(rmax - rmin), life / (double)(rmax - rmin) / 1024.0);
+        dprof = nullptr;
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), &dprof, sizeof(dprof)));
     }
     // accuracy on sampled rows
     std::vector<float> Cs((size_t)M * N);
@@ -863,8 +966,9 @@ int main() {
     srand(2020);
     const int M = 131072;   // both encoders of a B=64 step: 2 x 64 x 1024 points
     run<false, 3, 2, false, 3>("conv5", M, 512, 512, 1.f, 20);
-    run<false, 2, 2, false, 5>("conv5", M, 512, 512, 1.f, 20);
-    run<false, 2, 2, false, 5>("conv4", M, 512, 256, 1.f, 20);
-    run<false, 2, 2, false, 5>("conv3", M, 256, 128, 1.f, 20);
+    run<false, 2, 4, false, 3>("conv5", M, 512, 512, 1.f, 20);
+    run<false, 3, 2, false, 3>("conv4", M, 512, 256, 1.f, 20);
+    run<false, 3, 2, false, 3>("conv3", M, 256, 128, 1.f, 20);
+    run<false, 3, 2, false, 3>("conv2", M, 128, 64, 1.f, 20);
     return 0;
 }
