@@ -526,18 +526,15 @@ __global__ __launch_bounds__(256, MINB) void split_gemm3(const float* __restrict
         }
         return;
     }
-    if (store & 32) {   // the same loop with the phases pinned apart (no stamps)
+    if (store & 32) {   // the MFMA phase at raised wave priority
         for (int k0 = 0; k0 < K; k0 += BK) {
-            __builtin_amdgcn_sched_barrier(0);
             stage();
-            __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
-            __builtin_amdgcn_sched_barrier(0);
             if (k0 + BK < K) fetch(k0 + BK);
+            __builtin_amdgcn_s_setprio(3);
             compute();
-            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(0);
             __syncthreads();
-            __builtin_amdgcn_sched_barrier(0);
         }
     } else {
         for (int k0 = 0; k0 < K; k0 += BK) {
@@ -877,7 +874,7 @@ static void run(const char* name, int M, int N, int K, float xmag, int reps) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    for (int store : {1, 65, 193, 64}) {
+    for (int store : {65, 64, 97, 96}) {
         auto launch = [&]() {
             if (VER == 5)
                 hipLaunchKernelGGL((split_gemm5<MINB>), dim3(grid), dim3(256), 0, 0, dX, dWh, dWl, db, dC, M, N, K, sx, unscale, store);
@@ -966,9 +963,6 @@ int main() {
     srand(2020);
     const int M = 131072;   // both encoders of a B=64 step: 2 x 64 x 1024 points
     run<false, 3, 2, false, 3>("conv5", M, 512, 512, 1.f, 20);
-    run<false, 2, 4, false, 3>("conv5", M, 512, 512, 1.f, 20);
     run<false, 3, 2, false, 3>("conv4", M, 512, 256, 1.f, 20);
-    run<false, 3, 2, false, 3>("conv3", M, 256, 128, 1.f, 20);
-    run<false, 3, 2, false, 3>("conv2", M, 128, 64, 1.f, 20);
     return 0;
 }
