@@ -50,9 +50,6 @@ constexpr int oW4 = 0, oW3 = oW4 + 512 * 256, oW2 = oW3 + 256 * 128, oW1 = oW2 +
               oB3 = oB4 + 512, oB2 = oB3 + 256, oB1 = oB2 + 128;
 static_assert(oB1 + 64 == HP_EB_PART_FLOATS, "partial layout");
 
-#ifndef HP_EB_EXP
-#define HP_EB_EXP 0
-#endif
 #define HP_SB() __builtin_amdgcn_sched_barrier(0)
 
 __device__ __forceinline__ int drow(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }   // C/D map of 32x32 f32
@@ -314,20 +311,13 @@ __device__ __forceinline__ void chain_mfma4(const float* As, const float* __rest
         for (int g = 0; g < G; ++g)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-#if HP_EB_EXP & 8
-                if (g || s) { dst[g][s] = dst[0][0]; continue; }
-#endif
                 dst[g][s] = *reinterpret_cast<const float4*>(wp + (long)(c * 16 + 8 * g + s) * N);
             }
     };
     auto compute = [&](int c, const float4 (&src)[G][4]) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-#if HP_EB_EXP & 16
-            const float4 av = make_float4(src[g][0].x, src[g][1].y, src[g][2].z, src[g][3].w);
-#else
             const float4 av = *reinterpret_cast<const float4*>(&As[r * LDA + kA + c * 16 + 8 * g + 4 * h]);
-#endif
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const float a1 = f4at(av, s);
