@@ -589,7 +589,10 @@ def main():
                                                            else f"BASELINE.json configs[1] (3D-EPN chair, Chamfer+EMD) at B={args.batch}"
                                                            if args.batch == 32 else f"the metric's shape at B={args.batch}"),
                        "global_batch": args.batch * world, "points": args.points, "parallelism": f"dp{world}",
-                       "params": 43328515},
+                       "params": 43328515,
+                       "arithmetic": "fp32 operands, fp32 accumulation, fp32 outputs throughout; the encoders' conv GEMMs form their "
+                                     "products on the f16 matrix pipe from two f16 pieces per fp32 operand (three products, error vs "
+                                     "fp64 = the fp32 fma chain's: tests/test_model_gpu.py; HP_CONV_SPLIT=0 restores fp32 MFMA)"},
             "final_loss": loss,
         }
         if not args.no_extras:
