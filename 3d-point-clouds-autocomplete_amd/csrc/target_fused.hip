@@ -24,6 +24,7 @@
 //     (ordered, atomic-free).
 // HBM traffic: points + theta + y forward; points + theta + grad_y + S partial d theta backward.
 #include "hp_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -181,6 +182,196 @@ __global__ __launch_bounds__(512) void target_fwd_kernel(int N, int iters, const
         layer_fwd<4, 2, LD4>(lds + SW4, lds + SB4, h3, h4, r, h);
         float o[3];
         layer_out(lds, h4, h, o);
+        if (h == 0 && pt < N) {
+            Y[pt * 3] = o[0];
+            Y[pt * 3 + 1] = o[1];
+            Y[pt * 3 + 2] = o[2];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward on the f16 matrix pipe (round 3): the hidden layers' products from two f16 pieces per fp32 operand, three
+// v_mfma_f32_32x32x16_f16 per 32x32x16 block, fp32 accumulation — csrc/conv_split.hip's arithmetic (error vs fp64 = the fp32
+// chain's) with everything local to the workgroup:
+//   weights      per output channel: e_w = 14 - exponent(max_k |W[c,k]|), formed with the split while theta is staged into LDS;
+//   activations  per wave (its 32 points x all channels of the layer: the scale only has to be constant along the contraction).
+// "Points as columns" carries over: registers 8s..8s+7 of a 32x32 accumulator tile are, converted, the B operand of k-step s
+// of a 32x32x16 MFMA — lane half h then holds the channels 16s + 8(j>>2) + 4h + (j&3), j = 0..7 — and the weights' LDS image
+// stores each row with its 4-channel granules in that order (granule (s, g, h) at position (s, h, g)), so a lane's A fragment
+// is ONE ds_read_b128.  Rows are unpadded; the 16-byte chunk index is XOR-swizzled with the row so that the 16 rows a b128 read
+// touches per pass fall on different banks.  77 KB of fp32 weights become 72 KB of f16 pieces + 3 KB of fp32 vectors: still two
+// workgroups per CU.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// fp32 part of the forward's f16 LDS image (floats), then the f16 images (halfs, offsets from the halfs base)
+constexpr int FW1 = 0, FB1 = FW1 + C1 * 3, FW5 = FB1 + C1, FB5 = FW5 + 3 * C4, FB2 = FB5 + 4, FB3 = FB2 + C2, FB4 = FB3 + C3,
+              FS2 = FB4 + C4, FS3 = FS2 + C2, FS4 = FS3 + C3, kFwdFloats = FS4 + C4;
+static_assert(kFwdFloats % 4 == 0, "f16 images start 16-byte aligned");
+constexpr int HW2 = 0, HW3 = HW2 + 2 * C2 * C1, HW4 = HW3 + 2 * C3 * C2, kFwdHalfs = HW4 + 2 * C4 * C3;
+static_assert((kFwdFloats * 4 + kFwdHalfs * 2) * 2 <= 160 * 1024, "two forward workgroups per CU");
+
+template <int CIN>
+__device__ __forceinline__ int swz_chunk(int row, int chunk) {   // CIN halfs per row = CIN / 8 chunks of 16 bytes
+    return CIN == 32 ? (chunk ^ ((row >> 2) & 3)) : CIN == 64 ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ (row & 15));
+}
+
+__device__ __forceinline__ int f_frexp(float v) {   // e of v = f 2^e, f in [0.5, 1); 0 for zero / subnormal
+    const int E = (int)((__float_as_uint(v) >> 23) & 0xff);
+    return E ? E - 126 : 0;
+}
+__device__ __forceinline__ float f_pow2(int e) {
+    e = max(-126, min(127, e));
+    return __uint_as_float((unsigned)(e + 127) << 23);
+}
+
+// one hidden layer's weights (COUT x CIN, row-major in theta) -> hi / lo images + per-row unscale factors 2^-e_w
+template <int NT, int COUT, int CIN>
+__device__ __forceinline__ void split_rows(const float* __restrict__ src, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                           float* __restrict__ wsc, int tid) {
+    constexpr int TPR = CIN / 4;                       // threads per row (a power of two <= 32)
+    constexpr int UNITS = COUT * TPR;
+    for (int u0 = 0; u0 < UNITS; u0 += NT) {           // UNITS % NT == 0 or the tail is whole rows: TPR divides NT
+        const int u = u0 + tid;
+        const bool ok = u < UNITS;
+        const int row = ok ? u / TPR : 0, k0 = ok ? (u % TPR) * 4 : 0;
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = ok ? src[row * CIN + k0 + q] : 0.f;   // (theta rows are not 16-byte aligned)
+        float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        const int e = 14 - f_frexp(m);
+        const float sc = f_pow2(e);
+        f16x4 h4, l4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float xs = v[q] * sc;
+            const _Float16 hh = (_Float16)xs;
+            h4[q] = hh;
+            l4[q] = (_Float16)(xs - (float)hh);
+        }
+        if (ok) {
+            // granule k0 = 32 ti + 16 s + 8 g + 4 hh  ->  position 32 ti + 16 s + 8 hh + 4 g
+            const int g = (k0 >> 3) & 1, hh = (k0 >> 2) & 1, pos = (k0 & ~15) + 8 * hh + 4 * g;
+            const int off = row * CIN + swz_chunk<CIN>(row, pos >> 3) * 8 + (pos & 7);
+            *reinterpret_cast<f16x4*>(hi + off) = h4;
+            *reinterpret_cast<f16x4*>(lo + off) = l4;
+            if (k0 == 0) wsc[row] = f_pow2(-e);
+        }
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void load_theta_f16(const float* __restrict__ th, float* __restrict__ lf, _Float16* __restrict__ lh, int tid) {
+    split_rows<NT, C4, C3>(th + OW4, lh + HW4, lh + HW4 + C4 * C3, lf + FS4, tid);
+    split_rows<NT, C3, C2>(th + OW3, lh + HW3, lh + HW3 + C3 * C2, lf + FS3, tid);
+    split_rows<NT, C2, C1>(th + OW2, lh + HW2, lh + HW2 + C2 * C1, lf + FS2, tid);
+    for (int i = tid; i < C1 * 3 + C1; i += NT) lf[FW1 + i] = th[OW1 + i];            // W1, b1 (contiguous in both)
+    for (int i = tid; i < 3 * C4 + 3; i += NT) lf[FW5 + i] = th[OW5 + i];             // W5, b5
+    for (int i = tid; i < C2; i += NT) lf[FB2 + i] = th[OB2 + i];
+    for (int i = tid; i < C3; i += NT) lf[FB3 + i] = th[OB3 + i];
+    for (int i = tid; i < C4; i += NT) lf[FB4 + i] = th[OB4 + i];
+}
+
+// hidden layer on the f16 pipe: out (TO tiles) = relu(W (32*TO x 32*TI) . in (TI tiles) + b)
+template <int TI, int TO>
+__device__ __forceinline__ void layer_fwd_f16(const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
+                                              const float* __restrict__ wsc, const float* __restrict__ b, const f32x16 (&in)[TI],
+                                              f32x16 (&out)[TO], int r, int h) {
+    constexpr int CIN = 32 * TI;
+    // this wave's activation scale (post-ReLU values: >= 0)
+    float m = 0.f;
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) m = fmaxf(m, in[ti][e]);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    const int ex = 14 - f_frexp(m);
+    const float sx = f_pow2(ex), inv = f_pow2(-ex);
+    // the input tiles as B fragments, once (the fp32 copies die here); then ONE output tile at a time — a single accumulation
+    // chain of this MFMA needs no partner for throughput, and 16 + 8 instead of 32 + 16 registers keep two workgroups per CU
+    f16x8 bh[TI][2], bl[TI][2];
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xs = in[ti][8 * s + j] * sx;
+                const _Float16 hh = (_Float16)xs;
+                bh[ti][s][j] = hh;
+                bl[ti][s][j] = (_Float16)(xs - (float)hh);
+            }
+#pragma unroll
+    for (int to = 0; to < TO; ++to) {
+        const int row0 = to * 32 + r;
+        f32x16 acc0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc0[e] = 0.f;
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int o0 = row0 * CIN + swz_chunk<CIN>(row0, 4 * ti + 2 * s + h) * 8;
+                const f16x8 ah0 = *reinterpret_cast<const f16x8*>(Whi + o0), al0 = *reinterpret_cast<const f16x8*>(Wlo + o0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh[ti][s], acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl[ti][s], acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh[ti][s], acc0, 0, 0, 0);
+            }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int c0 = to * 32 + kmap(e, h);
+            out[to][e] = fmaxf(acc0[e] * (wsc[c0] * inv) + b[c0], 0.f);
+        }
+    }
+}
+
+__device__ __forceinline__ void layer1_at(const float* __restrict__ W1, const float* __restrict__ b1, float x, float y, float z, int h,
+                                          f32x16& h1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int c = kmap(e, h);
+        float t = x * W1[c * 3];
+        t = __builtin_fmaf(y, W1[c * 3 + 1], t);
+        t = __builtin_fmaf(z, W1[c * 3 + 2], t);
+        h1[e] = fmaxf(t + b1[c], 0.f);
+    }
+}
+
+__global__ __launch_bounds__(512) void target_fwd_f16_kernel(int N, int iters, const float* __restrict__ theta, int theta_ld,
+                                                             const float* __restrict__ pts, float* __restrict__ yout) {
+    __shared__ __attribute__((aligned(16))) float lf[kFwdFloats];
+    __shared__ __attribute__((aligned(16))) _Float16 lh[kFwdHalfs];
+    const int cloud = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    load_theta_f16<512>(theta + (long)cloud * theta_ld, lf, lh, tid);
+    __syncthreads();
+    const float* P = pts + (long)cloud * N * 3;
+    float* Y = yout + (long)cloud * N * 3;
+    for (int it = 0; it < iters; ++it) {
+        const int p0 = (blockIdx.x * iters + it) * 256 + wave * 32;
+        if (p0 >= N) break;
+        const int pt = p0 + r, pc = min(pt, N - 1);
+        const float x = P[pc * 3], y = P[pc * 3 + 1], z = P[pc * 3 + 2];
+        f32x16 h1[1], h2[2], h3[4], h4[2];
+        layer1_at(lf + FW1, lf + FB1, x, y, z, h, h1[0]);
+        layer_fwd_f16<1, 2>(lh + HW2, lh + HW2 + C2 * C1, lf + FS2, lf + FB2, h1, h2, r, h);
+        layer_fwd_f16<2, 4>(lh + HW3, lh + HW3 + C3 * C2, lf + FS3, lf + FB3, h2, h3, r, h);
+        layer_fwd_f16<4, 2>(lh + HW4, lh + HW4 + C4 * C3, lf + FS4, lf + FB4, h3, h4, r, h);
+        float o[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {   // output layer (64 -> 3) on the VALU, as layer_out
+            float t = 0.f;
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) t = __builtin_fmaf(lf[FW5 + c * C4 + ti * 32 + kmap(e, h)], h4[ti][e], t);
+            t += __shfl_xor(t, 32, 64);
+            o[c] = t + lf[FB5 + c];
+        }
         if (h == 0 && pt < N) {
             Y[pt * 3] = o[0];
             Y[pt * 3 + 1] = o[1];
@@ -533,7 +724,20 @@ int bwd_splits(int B, int N) {
     return s < 1 ? 1 : s;
 }
 
+bool g_fwd_f16 = [] {
+    const char* e = getenv("HP_TARGET_F16");
+    return !(e && e[0] == '0');
+}();
+
 }  // namespace
+
+// The fused forward's hidden layers on the f16 matrix pipe with split fp32 operands (default) or on the fp32 one (0; also
+// environment HP_TARGET_F16=0).  Returns the previous setting.
+HP_API int hp_target_fused_set_f16(int on) {
+    const int was = g_fwd_f16;
+    g_fwd_f16 = on != 0;
+    return was;
+}
 
 // 1 when (n_hidden, channels) is the architecture these kernels are written for
 HP_API int hp_target_fused_supported(int n_hidden, const int* channels) {
@@ -548,7 +752,10 @@ HP_API int hp_target_fused_forward(int B, int N, const float* theta, int theta_l
     int per = (blocks * B + 255) / 256;                // one resident workgroup per CU: theta is staged once per CU
     if (per < 1) per = 1;
     const int gx = (blocks + per - 1) / per;
-    hipLaunchKernelGGL(target_fwd_kernel, dim3(gx, B), dim3(512), 0, stream, N, per, theta, theta_ld, pts, y);
+    if (g_fwd_f16)
+        hipLaunchKernelGGL(target_fwd_f16_kernel, dim3(gx, B), dim3(512), 0, stream, N, per, theta, theta_ld, pts, y);
+    else
+        hipLaunchKernelGGL(target_fwd_kernel, dim3(gx, B), dim3(512), 0, stream, N, per, theta, theta_ld, pts, y);
     HP_RETURN_LAST_ERROR();
 }
 

@@ -320,6 +320,10 @@ int hp_target_backward(int B, int N, int n_hidden, const int* channels, const fl
  * hp_target_forward / hp_target_backward up to fp32 summation order. */
 int hp_target_fused_supported(int n_hidden, const int* channels);
 long hp_target_fused_workspace_floats(int B, int N);
+/* The fused target-network forward computes its hidden layers on the f16 matrix pipe from two f16 pieces per fp32 operand
+ * (csrc/target_fused.hip; the arithmetic of csrc/conv_split.hip with per-wave / per-channel scales).  0 selects the fp32 MFMA
+ * forward (also: environment HP_TARGET_F16=0).  Returns the previous setting. */
+int hp_target_fused_set_f16(int on);
 int hp_target_fused_forward(int B, int N, const float* theta, int theta_ld, const float* pts, float* y, hpStream_t stream);
 int hp_target_fused_backward(int B, int N, const float* theta, int theta_ld, const float* pts, const float* grad_y,
                              float* grad_theta, float* ws, hpStream_t stream);

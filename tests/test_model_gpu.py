@@ -524,6 +524,43 @@ def test_target_fused_c_abi_padded_theta_rows_and_determinism(ref):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("B,N,tscale,pscale", [(3, 700, 0.2, 1.0), (2, 2048, 0.05, 1.0), (4, 333, 1.5, 30.0), (2, 256, 0.01, 1e-3)])
+def test_target_fused_forward_f16_pipe_is_as_close_to_fp64_as_the_fp32_kernel(B, N, tscale, pscale):
+    """The fused decoder forward forms its hidden layers on the f16 matrix pipe from two f16 pieces per fp32 operand
+    (csrc/target_fused.hip; per-channel weight scales, per-wave activation scales).  Against an fp64 evaluation of the same
+    theta / points its error stays at the fp32 kernel's level, over weight and point scales that move the activations by 1e6."""
+    from hyperpocket_amd._lib import call, current_stream, load_library
+    lib = load_library()
+    g = torch.Generator(device="cuda").manual_seed(B * N)
+    T = 19011
+    theta = torch.randn(B, T, device="cuda", generator=g) * tscale
+    pts = (torch.rand(B, N, 3, device="cuda", generator=g) * 2 - 1) * pscale
+    # fp64 reference of model/target_network.py:31-38 on theta's layout [W1 b1 | W2 b2 | ... | Wo bo]
+    dims = [3, 32, 64, 128, 64, 3]
+    h, off = pts.double(), 0
+    for l in range(5):
+        cin, cout = dims[l], dims[l + 1]
+        W = theta[:, off:off + cout * cin].double().view(B, cout, cin); off += cout * cin
+        b = theta[:, off:off + cout].double().view(B, 1, cout); off += cout
+        h = torch.bmm(h, W.transpose(1, 2)) + b
+        if l < 4:
+            h = torch.relu(h)
+    want = h
+    scale = max(want.abs().max().item(), 1e-30)
+    err = {}
+    for f16 in (1, 0):
+        prev = lib.hp_target_fused_set_f16(f16)
+        try:
+            y = torch.empty(B, N, 3, device="cuda")
+            call("hp_target_fused_forward", B, N, theta, T, pts, y, current_stream(y.device))
+            torch.cuda.synchronize()
+        finally:
+            lib.hp_target_fused_set_f16(prev)
+        assert torch.isfinite(y).all()
+        err[f16] = (y.double() - want).abs().max().item() / scale
+    assert err[1] <= 3e-6 and err[1] <= 3 * err[0] + 2e-7, err
+
+
 def test_step_losses_kernel():
     """hp_step_losses: the four scalar terms of the engine's step in one launch."""
     from hyperpocket_amd._lib import call, current_stream
