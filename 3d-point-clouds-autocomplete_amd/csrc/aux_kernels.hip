@@ -72,12 +72,21 @@ __global__ __launch_bounds__(256) void sample_points_kernel(long total, float co
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kSliceMaxPts = 8192;
 
+// PLANES = false: candidate planes are Philox-drawn on the device and points are classified in fp32 (data augmentation at
+// device speed: the law of the reference, other draws).  PLANES = true: the caller supplies the candidate sequence
+// planes (B, R, 4) float64 = (params, bias) of HyperPlane — e.g. the planes numpy's generator gives the reference — and
+// every point is classified as HyperPlane.check_point does it (dataset_generator.py:10-11): float64
+// dot(point, params) + bias, products rounded before their adds; the accepted candidate's index is returned, so the
+// result is the reference's own split, bit for bit.
+template <bool PLANES>
 __global__ __launch_bounds__(256) void slice_kernel(int N, int target, const float* __restrict__ pts, unsigned long long seed,
-                                                    int max_rounds, float* __restrict__ part_a, float* __restrict__ part_b,
-                                                    float* __restrict__ plane_out, int* __restrict__ status) {
+                                                    int max_rounds, const double* __restrict__ planes, int R,
+                                                    float* __restrict__ part_a, float* __restrict__ part_b,
+                                                    float* __restrict__ plane_out, int* __restrict__ plane_idx,
+                                                    int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) float sp[];      // N*3 points
     __shared__ int wave_cnt[4];
-    __shared__ float sel[4];
+    __shared__ double sel[4];
     __shared__ int sel_flag, wsum[4];
     const int cloud = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const float* P = pts + (long)cloud * N * 3;
@@ -86,27 +95,46 @@ __global__ __launch_bounds__(256) void slice_kernel(int N, int target, const flo
     __syncthreads();
     const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
     int chosen_side = 0;   // +1: the "under" (check > 0) side has `target` points, -1: the other side
-    float a = 0, b = 0, c = 0, d = 0;
-    for (int round = 0; round < max_rounds; ++round) {
+    int chosen_idx = -1;
+    double a = 0, b = 0, c = 0, d = 0;
+    // `> 0` of np.sign(dot + bias): NaN compares false, as in the reference
+    auto under_of = [&](int i, double nx, double ny, double nz, double bias) -> bool {
+        if constexpr (PLANES)
+            return ((((double)sp[i * 3] * nx + (double)sp[i * 3 + 1] * ny) + (double)sp[i * 3 + 2] * nz) + bias) > 0.0;
+        else
+            return (sp[i * 3] * (float)nx + sp[i * 3 + 1] * (float)ny + sp[i * 3 + 2] * (float)nz + (float)bias) > 0.f;
+    };
+    const int rounds = PLANES ? (R + 3) / 4 : max_rounds;
+    for (int round = 0; round < rounds; ++round) {
         // wave-uniform candidate plane
-        const uint4 r0 = philox4x32_10(make_uint4((uint32_t)cloud, (uint32_t)round, (uint32_t)wid, 0u), key);
-        const uint4 r1 = philox4x32_10(make_uint4((uint32_t)cloud, (uint32_t)round, (uint32_t)wid, 1u), key);
-        const uint4 r2 = philox4x32_10(make_uint4((uint32_t)cloud, (uint32_t)round, (uint32_t)wid, 2u), key);
-        auto u01 = [](uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); };
-        const float p0x = u01(r0.x), p0y = u01(r0.y), p0z = u01(r0.z);
-        const float ux = u01(r1.x) - p0x, uy = u01(r1.y) - p0y, uz = u01(r1.z) - p0z;
-        const float vx = u01(r2.x) - p0x, vy = u01(r2.y) - p0y, vz = u01(r2.z) - p0z;
-        const float nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
-        const float bias = nx * p0x + ny * p0y + nz * p0z;         // HyperPlane(cp, np.dot(cp, points[0]))
+        double nx, ny, nz, bias;
+        bool have = true;
+        if constexpr (PLANES) {
+            const int idx = round * 4 + wid;
+            have = idx < R;
+            const double* pl = planes + ((long)cloud * R + (have ? idx : 0)) * 4;
+            nx = pl[0]; ny = pl[1]; nz = pl[2]; bias = pl[3];
+        } else {
+            const uint4 r0 = philox4x32_10(make_uint4((uint32_t)cloud, (uint32_t)round, (uint32_t)wid, 0u), key);
+            const uint4 r1 = philox4x32_10(make_uint4((uint32_t)cloud, (uint32_t)round, (uint32_t)wid, 1u), key);
+            const uint4 r2 = philox4x32_10(make_uint4((uint32_t)cloud, (uint32_t)round, (uint32_t)wid, 2u), key);
+            auto u01 = [](uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); };
+            const float p0x = u01(r0.x), p0y = u01(r0.y), p0z = u01(r0.z);
+            const float ux = u01(r1.x) - p0x, uy = u01(r1.y) - p0y, uz = u01(r1.z) - p0z;
+            const float vx = u01(r2.x) - p0x, vy = u01(r2.y) - p0y, vz = u01(r2.z) - p0z;
+            const float fx = uy * vz - uz * vy, fy = uz * vx - ux * vz, fz = ux * vy - uy * vx;
+            nx = fx; ny = fy; nz = fz;
+            bias = fx * p0x + fy * p0y + fz * p0z;                 // HyperPlane(cp, np.dot(cp, points[0]))
+        }
         int cnt = 0;
-        for (int i = lane; i < N; i += 64) cnt += (sp[i * 3] * nx + sp[i * 3 + 1] * ny + sp[i * 3 + 2] * nz + bias) > 0.f;
+        for (int i = lane; i < N; i += 64) cnt += under_of(i, nx, ny, nz, bias);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
-        if (lane == 0) wave_cnt[wid] = cnt;
+        if (lane == 0) wave_cnt[wid] = have ? cnt : -1;
         __syncthreads();
         if (tid == 0) {
             for (int w = 0; w < 4 && sel_flag < 0; ++w)
-                if (wave_cnt[w] == target || N - wave_cnt[w] == target) sel_flag = w;
+                if (wave_cnt[w] >= 0 && (wave_cnt[w] == target || N - wave_cnt[w] == target)) sel_flag = w;
         }
         __syncthreads();
         const int win = sel_flag;
@@ -117,17 +145,25 @@ __global__ __launch_bounds__(256) void slice_kernel(int N, int target, const flo
             __syncthreads();
             a = sel[0]; b = sel[1]; c = sel[2]; d = sel[3];
             chosen_side = (wave_cnt[win] == target) ? 1 : -1;      // the reference tests the "under" side first
+            chosen_idx = round * 4 + win;
             break;
         }
         __syncthreads();
     }
     if (chosen_side == 0) {
-        if (tid == 0) status[cloud] = 1;       // no plane found within max_rounds
+        if (tid == 0) {
+            status[cloud] = 1;       // no plane accepted within max_rounds*4 draws / among the R candidates
+            if (plane_idx) plane_idx[cloud] = -1;
+        }
         return;
     }
     if (tid == 0) {
         status[cloud] = 0;
-        plane_out[cloud * 4 + 0] = a; plane_out[cloud * 4 + 1] = b; plane_out[cloud * 4 + 2] = c; plane_out[cloud * 4 + 3] = d;
+        if (plane_idx) plane_idx[cloud] = chosen_idx;
+        if (plane_out) {
+            plane_out[cloud * 4 + 0] = (float)a; plane_out[cloud * 4 + 1] = (float)b;
+            plane_out[cloud * 4 + 2] = (float)c; plane_out[cloud * 4 + 3] = (float)d;
+        }
     }
     // order-preserving compaction: chunk of 256 points per iteration, exclusive scan of the membership flags
     float* A = part_a + (long)cloud * target * 3;
@@ -136,7 +172,7 @@ __global__ __launch_bounds__(256) void slice_kernel(int N, int target, const flo
     for (int i0 = 0; i0 < N; i0 += 256) {
         const int i = i0 + tid;
         bool under = false, valid = i < N;
-        if (valid) under = (sp[i * 3] * a + sp[i * 3 + 1] * b + sp[i * 3 + 2] * c + d) > 0.f;
+        if (valid) under = under_of(i, a, b, c, d);
         const bool in_a = valid && (chosen_side > 0 ? under : !under);
         const unsigned long long m = __ballot(in_a);
         const int before = __popcll(m & ((1ull << lane) - 1ull));
@@ -252,8 +288,22 @@ HP_API int hp_slice_clouds(int B, int N, int target, const float* pts, unsigned 
     HP_CHECK_ARG(B >= 0 && N > 0 && target > 0 && target < N && N <= kSliceMaxPts && max_rounds > 0);
     if (B == 0) return 0;
     HP_CHECK_ARG(pts && part_a && part_b && plane && status);
-    hipLaunchKernelGGL(slice_kernel, dim3(B), dim3(256), (size_t)N * 3 * sizeof(float), stream, N, target, pts, seed, max_rounds,
-                       part_a, part_b, plane, status);
+    hipLaunchKernelGGL(slice_kernel<false>, dim3(B), dim3(256), (size_t)N * 3 * sizeof(float), stream, N, target, pts, seed,
+                       max_rounds, (const double*)nullptr, 0, part_a, part_b, plane, (int*)nullptr, status);
+    HP_RETURN_LAST_ERROR();
+}
+
+// The same split with the CALLER's candidate planes: planes (B, R, 4) float64 on the device, cloud i tries
+// planes[i,0], planes[i,1], ... in order, classifying in float64 exactly as HyperPlane.check_point
+// (dataset_generator.py:10-11, 32-39); plane_idx (B) = index of the accepted candidate (-1 and status 1 if none of the
+// R was accepted).  With the planes numpy draws for the reference this IS the reference's split.
+HP_API int hp_slice_clouds_planes(int B, int N, int target, const float* pts, const double* planes, int R, float* part_a,
+                                  float* part_b, int* plane_idx, int* status, hipStream_t stream) {
+    HP_CHECK_ARG(B >= 0 && N > 0 && target > 0 && target < N && N <= kSliceMaxPts && R > 0);
+    if (B == 0) return 0;
+    HP_CHECK_ARG(pts && planes && part_a && part_b && plane_idx && status);
+    hipLaunchKernelGGL(slice_kernel<true>, dim3(B), dim3(256), (size_t)N * 3 * sizeof(float), stream, N, target, pts, 0ull, 0,
+                       planes, R, part_a, part_b, (float*)nullptr, plane_idx, status);
     HP_RETURN_LAST_ERROR();
 }
 

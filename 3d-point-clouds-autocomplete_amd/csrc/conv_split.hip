@@ -4,12 +4,20 @@
 // v_mfma_f32_32x32x2_f32 runs at 1/16 of the f16/bf16 matrix rate (MI355X_MICROARCH.md, Matrix cores) and these four GEMMs
 // (113.8 GFLOP per step for the two encoders) were 1.0 ms of a 3.6 ms step at 0.70-0.79 of THAT roofline.  Here every fp32
 // operand a is multiplied by an exact power of two and split into two f16 pieces
-//     a * 2^e = hi + lo + r,   hi = rne16(a 2^e),  lo = rne16(a 2^e - hi),  |r| <= 2^-24 |a 2^e|
-// (r is what an fp32 rounding discards), and a.b is formed as hi.hi + hi.lo + lo.hi by three v_mfma_f32_32x32x16_f16: exact
-// products, fp32 accumulation; the dropped lo.lo is <= 2^-24 |a b|.  Three f16 MFMAs per 32x32x16 block cost 96 cycles where
-// eight f32 ones cost 512.  Measured against fp64 on the step's shapes the result is as close as the k-ordered fp32 fma
-// chain of gemm.hip (rms error ratio 0.9-1.2, max 0.6-1.1: tools/micro/gemm_f16x2.hip; tests/test_model_gpu.py holds the
-// same comparison) — the arithmetic type of the path stays f32, only the rounding pattern differs.
+//     a * 2^e = hi + lo + r,   hi = rne16(a 2^e),  lo = rne16(a 2^e - hi),  |hi - a 2^e| <= 2^-11 |a 2^e|,  |r| <= 2^-23 |a 2^e|
+// (f16 carries 11 significant bits: after hi the residual has up to 13 bits of a's 24, lo keeps 11 or 12 of them, so r is zero
+// or ONE fp32 ulp of a — for roughly a quarter of the operands), and a.b is formed as hi.hi + hi.lo + lo.hi by three
+// v_mfma_f32_32x32x16_f16: exact products, fp32 accumulation; the dropped lo.lo is <= 2^-22 |a b|.  Operands are thus carried
+// to 22-23 bits, products to ~2^-22: "as close to fp64 as the fp32 chain" below is a MEASURED statement with stated factors
+// (rms <= 1.5x, max <= 2.5x the k-ordered fp32 fma chain's error, max <= 2e-6 of the layer's scale: tests/test_model_gpu.py
+// test_conv_stack_split_f16_is_as_close_to_fp64_as_the_fp32_chain), not a consequence of these bounds.
+// Three f16 MFMAs per 32x32x16 block cost 96 cycles where eight f32 ones cost 512.  Measured against fp64 on the step's
+// shapes: rms error ratio 0.9-1.2, max 0.6-1.5 against the fp32 chain of gemm.hip (tools/micro/gemm_f16x2.hip) — the
+// arithmetic type of the path stays f32, only the rounding pattern differs.
+// The BACKWARD of these layers (enc_bwd.hip) contracts with the unsplit fp32 weights and the stored activations: it is the
+// gradient of the fp32 layer, evaluated at activations the forward computed with W's 22-23-bit image — a 2^-22-relative
+// inconsistency between the function differentiated and the function evaluated, far inside the gradient bars (5e-4 against the
+// reference, 2e-5 against the fp64 oracle) and stated here so that nobody has to find it.
 //
 // Scales (f16 has 5 exponent bits; the split needs |a 2^e| in the normal range, and hi must not overflow):
 //   weights      per output channel (= per row of W): e_w[n] = 14 - exponent(max_k |W[n,k]|), formed with the split itself by

@@ -29,12 +29,8 @@
 #include <atomic>
 #include <cstdlib>
 
-// HP_EMD_DERIVE=1 (experiment, OFF): exp2 of the steeper level of a sweep derived as the 4th power of the milder one's.
-// Measured in round 3: -0.08 ms per step, but single match entries move by up to 2.8e-2 (bar 5e-3) and one EMD cost by
-// 4.5e-5 relative (bar 1e-5): the parity bars decide — not adopted.
-#ifndef HP_EMD_DERIVE
-#define HP_EMD_DERIVE 0
-#endif
+// (Round 3's derived-exponential experiment — e(j) = e(j+1)^4, -0.08 ms per step, fails the parity bars — lives as a patch in
+// tools/micro/emd_derive.patch, not in the shipped library: DESIGN.md 7b.)
 
 namespace {
 
@@ -215,16 +211,6 @@ __global__ __launch_bounds__(kThreads) void emd_rows1_kernel(Ctx c, int lev1, fl
                 const f2 d = sqdist2(PAIRC(lo, hi, u, 0) - px2[r], PAIRC(lo, hi, u, 1) - py2[r], PAIRC(lo, hi, u, 2) - pz2[r]);
                 // the running sums take their product through an fma — what nvcc's default -fmad=true makes of the
                 // reference's `w=...; suml+=w` (approxmatch.cu:86-87,185-189); the oracle's `contract` variant 3
-#if HP_EMD_DERIVE
-                if (DO3 && DO1) {
-                    // levels differ by exactly 4x (l3 = 4 * l1, a power-of-two scaling: l3*d = 4*(l1*d) bit for bit), so
-                    // exp2(l3*d) = exp2(l1*d)^4: two packed multiplies instead of a packed multiply and two v_exp_f32
-                    const f2 e1 = exp2_2(l1 * d), e1s = e1 * e1;
-                    acc3[r] = __builtin_elementwise_fma((e1s * e1s) * rl2[r], PAIRC(lo, hi, u, 3), acc3[r]);
-                    acc1[r] = __builtin_elementwise_fma(e1, f2{w[u * 2], w[u * 2 + 1]}, acc1[r]);
-                    continue;
-                }
-#endif
                 if (DO3) {
                     acc3[r] = __builtin_elementwise_fma(exp2_2(l3 * d) * rl2[r], PAIRC(lo, hi, u, 3), acc3[r]);   // (e * ratioL[k]) * ratioR[l]
                 }
@@ -391,25 +377,9 @@ __global__ __launch_bounds__(kThreads) void emd_rows2_kernel(Ctx c, int lev, flo
 template <bool ROW_IS_L>
 __device__ __forceinline__ f2 match_entry2(f2 d, const float (&row)[kLevels], const f32x16& lo, const f32x16& hi) {
     f2 acc = splat(0.f);
-#if HP_EMD_DERIVE
-    f2 ev[kLevels];      // levels 1, 3, 5, 7, 8 exact; 0, 2, 4, 6 as the 4th power of the next (one derivation step each)
-#pragma unroll
-    for (int lev = kLevels - 1; lev >= 0; --lev) {
-        if (lev == kLevels - 1 || (lev & 1)) {
-            ev[lev] = exp2_2(splat(level_l2e(lev)) * d);
-        } else {
-            const f2 s = ev[lev + 1] * ev[lev + 1];
-            ev[lev] = s * s;
-        }
-    }
-#endif
 #pragma unroll
     for (int lev = 0; lev < kLevels; ++lev) {
-#if HP_EMD_DERIVE
-        const f2 e = ev[lev];
-#else
         const f2 e = exp2_2(splat(level_l2e(lev)) * d);
-#endif
         const f2 cr = FINC(lo, hi, 3 + lev);
         // the level's term rides on an fma into the running sum (one rounding instead of the reference's two, i.e. a
         // slightly more accurate M; unlike the phase sweeps nothing downstream amplifies it: cost moves by ~1e-7 relative)
@@ -892,10 +862,8 @@ int emd_forward_impl(int b, int n, int m, const float* xyz1, const float* xyz2, 
     if (rc) return rc;
     c.acc_scale = acc_scale;
     if (after && after != stream) {   // the accumulated-into gradient was written on `after`: order the sweep behind it
-        static hipEvent_t ev = nullptr;
-        if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
-        if (hipEventRecord(ev, after) != hipSuccess) return (int)hipGetLastError();
-        if (hipStreamWaitEvent(stream, ev, 0) != hipSuccess) return (int)hipGetLastError();
+        rc = hp_order_streams(after, stream);
+        if (rc) return rc;
     }
     const int nb = (n + kRowsPerWg - 1) / kRowsPerWg, mb = (m + kRowsPerWg - 1) / kRowsPerWg;
     if (grad2) {

@@ -22,7 +22,7 @@
 // No atomics, fixed summation orders: run-to-run identical; per row the arithmetic does not depend on how many encoders
 // share the launches.
 //
-// What shaped it (measured, tools/micro/enc_bwd_probe.hip + HP_EB_PROF stamps; DESIGN.md §3.3):
+// What shaped it (measured, tools/micro/enc_bwd_probe.hip + HP_EB_PROF stamps; DESIGN.md §3.5):
 //  * a grid of 16 row blocks per cloud leaves the dead blocks interleaved with the live ones and XCDs 6, 7 without a live
 //    block: 296 us against 168 with the live blocks as the first, contiguous ids;
 //  * hipcc sinks prefetch loads behind the MFMA block that should cover them, and a load inside a branch makes the waitcnt

@@ -16,6 +16,10 @@
         if (!(cond)) return -1; \
     } while (0)
 
+// stream_order.hip: everything enqueued on `to` afterwards starts behind everything enqueued on `from` so far (an event per
+// (device, from) under a mutex).  0 or a hipError_t.
+int hp_order_streams(hipStream_t from, hipStream_t to);
+
 namespace hp {
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -901,11 +901,7 @@ inline bool a16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) ==
 // `after` (may be NULL): a stream to be ordered behind the tails' launches (event record on `stream`, wait on `after`).
 int order_behind(hipStream_t stream, hipStream_t after) {
     if (!after || after == stream) return 0;
-    static hipEvent_t ev = nullptr;      // one device per process; re-recording an event is legal, waits bind to the record they follow
-    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
-    if (hipEventRecord(ev, stream) != hipSuccess) return (int)hipGetLastError();
-    if (hipStreamWaitEvent(after, ev, 0) != hipSuccess) return (int)hipGetLastError();
-    return 0;
+    return hp_order_streams(stream, after);
 }
 
 int encoder_backward_fused(int B, int Np, int out_size, int n, const HpEncoderBwdIO* io, hipStream_t stream, hipStream_t after) {

@@ -129,8 +129,16 @@ class FusedHeadsAdam:
         that need empty SIMDs — would sit behind it for that long.  The encoder pair's backward launches it behind its
         tails instead (`launch_ordered`, ops.EncoderPairFunction), beside the matrix-bound conv-stack launches;
         `flush` launches it at the latest when backward is over (modes without the paired encoders)."""
+        if self.ran or self._job is not None:
+            # The owner's step() (FlatAdam.step / TrainEngine.step) consumes a fused pass and clears `ran`.  A second
+            # backward() before that would update the heads' weights AGAIN with the same bias-correction step number —
+            # silently (their .grad is None: clip_grad_norm_ / GradScaler never see them).  Fail loudly instead.
+            raise RuntimeError(
+                "FusedHeadsAdam: backward() reached the hypernetwork heads again before the optimiser's step() consumed the "
+                "previous pass (their weights were already updated in place during that backward).  Call step() after every "
+                "backward(); for gradient accumulation, skipped steps or a second backward build FlatAdam(model, ..., "
+                "fuse_heads=False) / TrainEngine(..., fuse_heads_adam=False).")
         self._job = (grad_theta, t5)
-        self.ran = False
         if self.stream is None or not self.defer:
             self.flush()
 
@@ -165,6 +173,15 @@ class FusedHeadsAdam:
 
     def join(self):
         self.flush()
+        if self.stream is not None and self._keep is not None:
+            torch.cuda.current_stream(self.flat.flat.device).wait_stream(self.stream)
+        self._keep = None
+
+    def abort(self):
+        """The step in flight failed: a pass that was handed over but not launched is DROPPED (launching it would move
+        weights and moments of a step that is not counted; a retry would apply the update twice with one bias-correction
+        step number), a pass already running on the side stream is waited for."""
+        self._job = None
         if self.stream is not None and self._keep is not None:
             torch.cuda.current_stream(self.flat.flat.device).wait_stream(self.stream)
         self._keep = None
@@ -279,13 +296,14 @@ class TrainEngine:
             torch.autograd.backward(roots, root_grads)
         except BaseException:
             if self.fused is not None:
-                self.fused.join()               # the side stream must not outlive the failed step
+                self.fused.abort()              # drop an unlaunched pass; the side stream must not outlive the failed step
             raise
+        else:
+            if self.fused is not None:
+                self.fused.flush()              # (modes without the paired encoders' backward; a no-op otherwise)
         finally:
             model.hyper_network._heads_exchange = None
             model._after_encoder_tails = None
-            if self.fused is not None:
-                self.fused.flush()              # (modes without the paired encoders' backward; a no-op otherwise)
             args, self._deferred_losses = self._deferred_losses, None
             if args is not None:
                 call("hp_step_losses", *args, current_stream(device))

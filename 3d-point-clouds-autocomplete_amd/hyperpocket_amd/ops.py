@@ -437,19 +437,33 @@ def sample_points(B, N, coef, seed, offset, device):
     return out
 
 
-def slice_clouds(points, target=1024, seed=0, max_rounds=100000):
+def slice_clouds(points, target=1024, seed=0, max_rounds=100000, planes=None):
     """Random-plane slicer (datasets/utils/dataset_generator.py:26-39) for a batch of clouds on the device.
-    points (B,N,3) -> (part_with_target_points (B,target,3), rest (B,N-target,3), plane (B,4))."""
+    points (B,N,3) -> (part_with_target_points (B,target,3), rest (B,N-target,3), plane).
+    planes=None: candidate planes are drawn on the device (Philox(seed)), fp32 classification; plane = (B,4) float32, the
+    accepted plane.  planes = (B,R,4) or (R,4) float64 candidate (params, bias) rows — e.g. the sequence numpy's generator
+    gives the reference: float64 classification exactly as HyperPlane.check_point, the reference's own split; plane = (B,)
+    int32, the index of the accepted candidate."""
     points = points.contiguous()
     check_input(points, "points")
     B, N = points.size(0), points.size(1)
     dev = points.device
     a = torch.empty((B, target, 3), dtype=torch.float32, device=dev)
     b = torch.empty((B, N - target, 3), dtype=torch.float32, device=dev)
-    plane = torch.empty((B, 4), dtype=torch.float32, device=dev)
     status = torch.empty((B,), dtype=torch.int32, device=dev)
-    call("hp_slice_clouds", B, N, target, points, ctypes.c_ulonglong(seed & (2 ** 64 - 1)), max_rounds, a, b, plane, status,
-         current_stream(dev))
+    if planes is not None:
+        planes = torch.as_tensor(planes, dtype=torch.float64).to(dev)
+        if planes.dim() == 2:
+            planes = planes.unsqueeze(0).expand(B, -1, -1)
+        if planes.dim() != 3 or planes.size(0) != B or planes.size(2) != 4 or planes.size(1) == 0:
+            raise HipExtensionError("planes must be (B,R,4) or (R,4) float64 with R > 0")
+        planes = planes.contiguous()
+        plane = torch.empty((B,), dtype=torch.int32, device=dev)
+        call("hp_slice_clouds_planes", B, N, target, points, planes, planes.size(1), a, b, plane, status, current_stream(dev))
+    else:
+        plane = torch.empty((B, 4), dtype=torch.float32, device=dev)
+        call("hp_slice_clouds", B, N, target, points, ctypes.c_ulonglong(seed & (2 ** 64 - 1)), max_rounds, a, b, plane, status,
+             current_stream(dev))
     if int(status.max().item()) != 0:     # data preparation, not the training step: a host sync is fine here
         raise HipExtensionError(f"no plane with a {target}-point side found for {int((status != 0).sum())} cloud(s)")
     return a, b, plane

@@ -16,7 +16,10 @@ reference's `{epoch}_O.pth`), and behind it the engine's machinery:
   one kernel behind the hypernetwork's backward forms it tile by tile and applies Adam in place
   (`hp_hypernet_heads_dw_adam`, `core.engine.FusedHeadsAdam`).  The heads' `.grad` then stays `None` and their weights
   move during `backward()` — equivalent for every loop that calls `step()` after each `backward()` (the reference's
-  does); pass `fuse_heads=False` for gradient accumulation or gradient inspection.
+  does).  A loop that does NOT — a skipped step after a non-finite loss, gradient accumulation, a second backward —
+  would update the heads twice with one bias-correction step number; that is detected and raised (at the second
+  backward, or at the next `zero_grad()`), never silent.  Pass `fuse_heads=False` for such loops or for gradient
+  inspection (`clip_grad_norm_` / `GradScaler` cannot see the heads while their `.grad` is None).
 
 Update arithmetic: `hp_adam_step` performs torch.optim.Adam's operations in its order (wd = 0, amsgrad = False — the
 reference's settings); tests/test_model_gpu.py compares the two over several steps.
@@ -65,6 +68,11 @@ class FlatAdam(torch.optim.Optimizer):
         return self.param_groups[0]["eps"]
 
     def zero_grad(self, set_to_none=True):
+        if self.fused is not None and (self.fused.ran or self.fused.pending()):
+            raise RuntimeError(
+                "FlatAdam.zero_grad(): the previous backward() already applied (or queued) the fused Adam update of the "
+                "hypernetwork heads, but step() was not called for it — the rest of the model would miss that step.  Call "
+                "step() after every backward(), or build FlatAdam(model, ..., fuse_heads=False).")
         self.flat.clear_param_grads()
 
     @torch.no_grad()

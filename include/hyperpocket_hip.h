@@ -12,6 +12,13 @@
  *     (the reference throws std::runtime_error("CUDA kernel failed : <code>"),
  *      approxmatch.cu:334-337; its nndistance launchers check nothing, nndistance.cu:131-160).
  * Layouts are the reference's: point sets (b, n, 3) fp32 contiguous, indices int32.
+ *
+ * TEST HOOKS.  hp_emd_set_rows_per_lane, hp_encoder_backward_set_fused, hp_conv_split_set, hp_skinny_set_enabled,
+ * hp_target_fused_set_f16 (and hp_conv_presplit_set below) flip PROCESS-WIDE switches that select between implementations of
+ * the same result; they exist so that the parity tests can hold every implementation against the oracle in one process.  They
+ * are plain globals: not thread-safe, not per-stream, not meant to be called while another host thread is inside the library.
+ * A production caller never needs them (the defaults are the measured-fastest paths; the environment variables named at each
+ * hook set the same switch once at load time).
  */
 #ifndef HYPERPOCKET_HIP_H
 #define HYPERPOCKET_HIP_H
@@ -53,6 +60,7 @@ int hp_approxmatch_ws(int b, int n, int m, const float* xyz1, const float* xyz2,
  * kernel) and rows2 (phase 2) in {0,1,2,4}, grad2 (final cost/gradient sweep) in {0,1,2}; 0 = the size heuristic.
  * Process-wide.  Every setting evaluates each row with the same operations in the same order (results identical bit
  * for bit; tests/test_structural_losses_gpu.py). */
+/* [test hook: process-wide, not thread-safe — see the header comment] */
 int hp_emd_set_rows_per_lane(int rows1, int rows2, int grad2);
 
 /* Match-free EMD (what match_cost.py:9-46 computes through ApproxMatch + MatchCost + MatchCostGrad, without ever
@@ -256,10 +264,12 @@ int hp_encoder_backward_pair_ordered(int B, int Np, int out_size, const HpEncode
 /* Parity-test switch: 0 sends every encoder backward through round 2's layered launch sequence (sort, gather, a dX GEMM,
  * a dW GEMM and a split-K reduce per layer), 1 (default) through the fused kernels when fwd_ws != NULL and dedup != 0.
  * Returns the previous setting. */
+/* [test hook: process-wide, not thread-safe — see the header comment] */
 int hp_encoder_backward_set_fused(int on);
 /* The encoders' conv stack (model/encoder.py:14-28) runs on the f16 matrix pipe with every fp32 operand split into two
  * f16 pieces (three MFMA products per block; as close to fp64 as the fp32 fma chain — csrc/conv_split.hip).  0 sends it
  * through the fp32 MFMA GEMMs instead (also: environment HP_CONV_SPLIT=0).  Returns the previous setting. */
+/* [test hook: process-wide, not thread-safe — see the header comment] */
 int hp_conv_split_set(int on);
 /* The same split-f16 GEMM as a stand-alone primitive: C = act(X W^T + b), X (M,K) and W (N,K) fp32 of either sign, row-major;
  * N % 128 == 0, K % 32 == 0, K <= 512.  prepare forms max|X| per 128-row tile and the f16 pieces / per-row exponents of W in ws
@@ -300,6 +310,7 @@ int hp_hypernet_heads_dw_adam(int Kc, int rows, int r0, const float* dtheta_all,
  * launch per phase (layer), ordered by the kernel boundary, no reduce launches: csrc/skinny.hip; the one-persistent-launch
  * variant with a grid-wide barrier was measured and dropped — when their shapes allow, otherwise as tiled GEMM launches.  Diagnostic switch for parity tests: 0 forces the GEMM launches, 1 the layer programs, -1 the default
  * (on; HP_SKINNY=0 in the environment turns it off).  Returns the previous setting.  No reference counterpart. */
+/* [test hook: process-wide, not thread-safe — see the header comment] */
 int hp_skinny_set_enabled(int on);
 
 /* The B per-cloud TargetNetworks of one step at once (model/full_model.py:70-74, model/target_network.py:6-45).
@@ -323,6 +334,7 @@ long hp_target_fused_workspace_floats(int B, int N);
 /* The fused target-network forward computes its hidden layers on the f16 matrix pipe from two f16 pieces per fp32 operand
  * (csrc/target_fused.hip; the arithmetic of csrc/conv_split.hip with per-wave / per-channel scales).  0 selects the fp32 MFMA
  * forward (also: environment HP_TARGET_F16=0).  Returns the previous setting. */
+/* [test hook: process-wide, not thread-safe — see the header comment] */
 int hp_target_fused_set_f16(int on);
 /* Prototype switch, off by default: the fused backward with its forward recomputation and dX contractions on the f16 pipe
  * (parity-tested; not faster than the fp32 kernel yet — DESIGN.md 7b).  Returns the previous setting. */
@@ -342,6 +354,13 @@ int hp_sample_points(long total, float coef, unsigned long long seed, unsigned l
  * plane (B,4) = normal + bias of the accepted plane; status (B) int: 0 ok, 1 none accepted in max_rounds*4 draws. */
 int hp_slice_clouds(int B, int N, int target, const float* pts, unsigned long long seed, int max_rounds, float* part_a,
                     float* part_b, float* plane, int* status, hpStream_t stream);
+/* The same split with the CALLER's candidate planes: planes (B, R, 4) float64 device memory = (params, bias) of
+ * dataset_generator.py:6-8's HyperPlane; cloud i tries planes[i,0..R) in order and classifies every point in float64 exactly
+ * as HyperPlane.check_point (:10-11) — with the planes numpy's generator hands the reference, part_a / part_b ARE
+ * SlicedDatasetGenerator.generate_item's two return values (tests/golden/slicer.npz).  plane_idx (B): index of the accepted
+ * candidate, -1 (and status 1) when none of the R was accepted. */
+int hp_slice_clouds_planes(int B, int N, int target, const float* pts, const double* planes, int R, float* part_a,
+                           float* part_b, int* plane_idx, int* status, hpStream_t stream);
 /* KLD term of core/epoch_loops.py:29-30 and its gradients */
 int hp_kld_forward(long n, int batch, const float* explv, const float* mu, float* out, hpStream_t stream);
 int hp_kld_backward(long n, int batch, const float* explv, const float* mu, const float* grad_out, float* grad_explv,

@@ -295,6 +295,10 @@ def test_conv_stack_split_outlier_point_costs_only_its_tile():
             want = torch.relu(prev.double() @ params[l].double().t() + params[5 + l].double())
             rel = (hs[l].double() - want).abs() / want.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
             w = max(w, rel[128:].max().item())              # every row outside the outlier's tile
+            # ... and what the outlier's 127 tile-mates DO pay (stated, not hidden): their error is bounded relative to the
+            # TILE's largest activation (the scale the pieces are formed in), not relative to their own row
+            tile_err = (hs[l].double() - want).abs()[:128].max().item() / want[:128].abs().max().item()
+            assert tile_err <= 2e-6, (split, l, tile_err)
             prev = hs[l]
         worst[split] = w
     assert worst[True] <= 2e-6 and worst[True] <= 3 * worst[False] + 1e-7, worst
@@ -1163,6 +1167,52 @@ def test_dropin_route_equals_engine_and_flat_adam_equals_torch_adam():
         grad_close(sd["state"][i_w]["exp_avg"], o_t.state[m_t.hyper_network.output[3].weight]["exp_avg"], tol=1e-5)
         o_f.load_state_dict(ref_opt.state_dict())
         assert o_f.steps == 3
+    finally:
+        ops.clear_grad_views()
+
+
+def test_flat_adam_fails_loudly_when_step_is_skipped_after_a_fused_backward():
+    """with fuse_heads=True the heads' Adam update is applied inside backward().  A loop that skips
+    step() (non-finite-loss skip, gradient accumulation, a second backward) must not update them twice silently: the second
+    backward — and the next zero_grad() — raise; fuse_heads=False serves such loops (the heads' .grad is then a tensor)."""
+    from hyperpocket_amd import ops
+    from hyperpocket_amd.losses.champfer_loss import ChamferLoss
+    from hyperpocket_amd.optim import FlatAdam
+    g = torch.Generator().manual_seed(5)
+    ex, mi = torch.rand(3, 64, 3, generator=g) - 0.5, torch.rand(3, 64, 3, generator=g) - 0.5
+    gt = torch.cat([ex, mi], 1).cuda()
+    dev = torch.device("cuda")
+    loss_fn = ChamferLoss().to(dev)
+
+    def loss_of(model):
+        rec, logvar, mu = model(ex.clone().to(dev), mi.clone().to(dev), list(gt.shape), 1, dev)
+        return torch.mean(0.05 * loss_fn(gt, rec.permute(0, 2, 1)))
+
+    try:
+        model = build_model(7).train()
+        opt = FlatAdam(model, lr=1e-4)
+        opt.zero_grad()
+        loss_of(model).backward()
+        with pytest.raises(RuntimeError, match="step\\(\\)"):
+            opt.zero_grad()                                   # step() skipped: the heads already moved
+        with pytest.raises(RuntimeError, match="FusedHeadsAdam"):
+            loss_of(model).backward()                         # ... and a second backward would move them again
+        opt.step()                                            # consuming the pass clears the condition
+        opt.zero_grad()
+        loss_of(model).backward()
+        opt.step()
+        assert opt.steps == 2
+        torch.cuda.synchronize()
+        ops.clear_grad_views()
+        model = build_model(7).train()
+        opt = FlatAdam(model, lr=1e-4, fuse_heads=False)
+        opt.zero_grad()
+        loss_of(model).backward()
+        assert model.hyper_network.output[3].weight.grad is not None
+        opt.zero_grad()                                       # a skipped step is the caller's business here
+        loss_of(model).backward()
+        opt.step()
+        torch.cuda.synchronize()
     finally:
         ops.clear_grad_views()
 

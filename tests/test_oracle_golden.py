@@ -252,3 +252,17 @@ def test_oracle_under_address_and_ub_sanitizers():
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "sanitize"], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert r.stdout.count(": ok") == 9 and "BAD" not in r.stdout
+
+
+def test_slicer_oracle_reproduces_the_reference_fixture():
+    """N3: oracle/slicer_ref.py against tests/golden/slicer.npz — the reference's own generate_item outputs
+    (datasets/utils/dataset_generator.py:29-39) under seeded np.random, with the planes it drew as inputs."""
+    from oracle.slicer_ref import slice_with_planes
+    g = golden("slicer")
+    for name in g["cases"]:
+        pts, planes = g[f"{name}_points"], g[f"{name}_planes"]
+        a, b, idx = slice_with_planes(pts, planes, g[f"{name}_part_a"].shape[0])
+        assert idx == int(g[f"{name}_accepted"]), name
+        assert np.array_equal(a, g[f"{name}_part_a"]) and np.array_equal(b, g[f"{name}_part_b"]), name
+        # the planes past the accepted one are never reached; without the accepted one the split changes or fails
+        assert slice_with_planes(pts, planes[:idx], a.shape[0])[2] == -1, name

@@ -43,3 +43,68 @@ def test_slicer_uneven_target_and_dataset_generator_api():
     batch = torch.rand(5, 2048, 3, device="cuda", generator=g) - 0.5
     ex, mi = SlicedDatasetGenerator.generate_batch(batch, 1024, seed=11)
     assert ex.shape == (5, 1024, 3) and mi.shape == (5, 1024, 3)
+
+
+def test_slicer_with_the_reference_planes_is_the_reference_split_bit_for_bit():
+    """N3, rule (f): tests/golden/slicer.npz holds what the reference's own SlicedDatasetGenerator.generate_item
+    (datasets/utils/dataset_generator.py:29-39) returned under a seeded np.random, plus the candidate planes
+    HyperPlane.get_random_plane drew for it.  hp_slice_clouds_planes classifies in float64 as check_point (:10-11):
+    accepted-plane index and both parts must be IDENTICAL — through ops.slice_clouds and through the C ABI."""
+    import ctypes
+    from conftest import golden
+    from hyperpocket_amd import load_library
+    from hyperpocket_amd.datasets.utils.dataset_generator import SlicedDatasetGenerator
+    from hyperpocket_amd.ops import slice_clouds
+    from oracle.slicer_ref import slice_with_planes
+    g = golden("slicer")
+    lib = load_library()
+    for name in g["cases"]:
+        pts, planes = g[f"{name}_points"], g[f"{name}_planes"]
+        want_a, want_b, want_idx = g[f"{name}_part_a"], g[f"{name}_part_b"], int(g[f"{name}_accepted"])
+        target = want_a.shape[0]
+        P = torch.from_numpy(pts).cuda()
+        a, b, idx = slice_clouds(P.unsqueeze(0), target, planes=planes)
+        assert int(idx[0]) == want_idx, (name, int(idx[0]), want_idx)
+        assert np.array_equal(a[0].cpu().numpy(), want_a) and np.array_equal(b[0].cpu().numpy(), want_b), name
+        # the reference-shaped call
+        pa, pb = SlicedDatasetGenerator.generate_item(P, target, planes=planes)
+        assert np.array_equal(pa.cpu().numpy(), want_a) and np.array_equal(pb.cpu().numpy(), want_b), name
+        # raw C ABI, two clouds sharing the launch with DIFFERENT candidate lists: cloud 1 gets the list without its
+        # first 3 candidates -> the accepted index shifts by 3, same parts
+        if want_idx >= 3:
+            R = planes.shape[0] - 3
+            pl2 = torch.from_numpy(np.stack([planes[:R], planes[3:]])).cuda()
+            P2 = P.unsqueeze(0).repeat(2, 1, 1).contiguous()
+            N = pts.shape[0]
+            A = torch.empty(2, target, 3, device="cuda"); Bt = torch.empty(2, N - target, 3, device="cuda")
+            pi = torch.empty(2, dtype=torch.int32, device="cuda"); st = torch.empty(2, dtype=torch.int32, device="cuda")
+            rc = lib.hp_slice_clouds_planes(2, N, target, ctypes.c_void_p(P2.data_ptr()), ctypes.c_void_p(pl2.data_ptr()), R,
+                                            ctypes.c_void_p(A.data_ptr()), ctypes.c_void_p(Bt.data_ptr()),
+                                            ctypes.c_void_p(pi.data_ptr()), ctypes.c_void_p(st.data_ptr()), None)
+            assert rc == 0
+            torch.cuda.synchronize()
+            assert pi.tolist() == [want_idx, want_idx - 3] and st.tolist() == [0, 0], (name, pi.tolist())
+            for c in range(2):
+                assert np.array_equal(A[c].cpu().numpy(), want_a) and np.array_equal(Bt[c].cpu().numpy(), want_b), name
+        # a candidate list that ends before the accepted plane: status 1 -> HipExtensionError, as documented
+        from hyperpocket_amd import HipExtensionError
+        if want_idx > 0:
+            with pytest.raises(HipExtensionError):
+                slice_clouds(P.unsqueeze(0), target, planes=planes[:want_idx])
+    # seeded clouds beyond the fixture: the kernel against the numpy restatement of the reference (oracle/slicer_ref.py,
+    # itself pinned by the fixture on CPU), planes drawn here the way the reference draws them
+    rs = np.random.RandomState(5)
+    for N, target in ((2048, 1024), (1000, 400), (64, 32), (4097, 2048)):
+        B = 3
+        pts = (rs.random_sample((B, N, 3)) - 0.5).astype(np.float32)
+        R = 6000
+        tri = rs.random_sample((B, R, 3, 3))
+        cp = np.cross(tri[:, :, 1] - tri[:, :, 0], tri[:, :, 2] - tri[:, :, 0])
+        planes = np.concatenate([cp, (cp * tri[:, :, 0]).sum(-1, keepdims=True)], -1)
+        planes[:, :, 3] -= 0.5 * cp.sum(-1)                    # through the cloud's cube, so that a split exists within R
+        want = [slice_with_planes(pts[c], planes[c], target) for c in range(B)]
+        assert all(w[2] >= 0 for w in want), (N, target)      # seeded: every cloud finds its split within R
+        a, b, idx = slice_clouds(torch.from_numpy(pts).cuda(), target, planes=planes)
+        for c in range(B):
+            assert int(idx[c]) == want[c][2], (N, target, c)
+            assert np.array_equal(a[c].cpu().numpy(), want[c][0]) and np.array_equal(b[c].cpu().numpy(), want[c][1])
