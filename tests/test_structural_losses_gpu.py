@@ -633,7 +633,10 @@ def test_emd_cost_error_distribution_at_full_size(oracle_lib):
     """The EMD cost north_star gates at 1e-5, MAPPED instead of sampled: hp_emd_forward (the engine's call, B = regime
     size, N = 2048) against the C oracle under the kernels' contraction (3) and the literal source (0) on 208 clouds in four
     regimes.  Asserted: every cloud whose cost carries mass (> 1e-3; a matched cloud's is O(10..1000)) within 1e-5
-    relative, 99th percentile within 3e-6; the distribution is printed (pytest -s) and quoted in DESIGN.md 2."""
+    relative (the gate), 99th percentile within 2e-6; the distribution is printed (pytest -s) and quoted in DESIGN.md 2.
+    Measured in round 4 (MI355X): max 7.6e-7, p99 <= 6.4e-7, median 0..1.6e-7 in every regime and under both contractions —
+    the 1.16e-5 DESIGN.md 3.6 once saw at the untrained-network operating point belonged to a cloud WITHOUT mass (33 of that
+    regime's 48 clouds: every exponential underflows, cost ~1e-24), which is why that comparison carries an atol."""
     regimes = _emd_regimes()
     regimes["untrained network (rec O(1e2))"] = _untrained_network_regime()
     total, lines = 0, []
@@ -655,7 +658,7 @@ def test_emd_cost_error_distribution_at_full_size(oracle_lib):
                 lines.append(f"{name:32s} contract={contract}: {int(mass.sum()):3d}/{len(want)} clouds with mass, cost "
                              f"{want[mass].min():.3g}..{want[mass].max():.3g}, rel err median {p50:.2e} p99 {p99:.2e} max {mx:.2e}")
                 assert mx <= 1e-5, lines[-1]
-                assert p99 <= 1e-5, lines[-1]
+                assert p99 <= 2e-6, lines[-1]
             else:
                 lines.append(f"{name:32s} contract={contract}: no cloud with mass (all {len(want)} costs < 1e-3)")
         total += len(gt)
