@@ -75,6 +75,8 @@ struct PrepParams {
     unsigned* amax;           // 4 * tiles_pad words to clear (the per-tile maxima of layers 1..4)
     long n_amax;
     long sArea;               // distance (floats) between the two encoders' split areas
+    int* fmt;                 // the workspace's format word (hp_conv_split.h)
+    int fmt_value;
 };
 constexpr int kRows[5] = {0, 128, 384, 896, 1408};                 // first row of layer 2..5 in wexp
 constexpr long kWOff[4] = {0, 8192, 40960, 172032};                // first element of layer 2..5 in hi / lo
@@ -84,6 +86,7 @@ __global__ __launch_bounds__(256) void conv_split_prep_kernel(const PrepParams p
     const int z = blockIdx.y, lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.n_amax; i += (long)gridDim.x * 256) p.amax[z * p.sArea + i] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) p.fmt[z * p.sArea] = p.fmt_value;
     int l = 0;
     while (l < 3 && row >= kRows[l + 1]) ++l;
     const int n = row - kRows[l], K = kK[l];
@@ -434,7 +437,7 @@ bool g_enabled = [] {
 
 }  // namespace
 
-long hp_conv_split_area_floats(long R) { return HP_CS_AMAX_OFF + 4 * hp_conv_split_tiles_pad(R); }
+long hp_conv_split_area_floats(long R) { return HP_CS_AMAX_OFF + 9 * hp_conv_split_tiles_pad(R) + 4; }   // amax x 4, P-format exponents x 5, format word
 bool hp_conv_split_enabled() { return g_enabled; }
 HP_API int hp_conv_split_set(int on) {
     const int was = g_enabled;
@@ -442,7 +445,7 @@ HP_API int hp_conv_split_set(int on) {
     return was;
 }
 
-int hp_conv_split_prep(int n, const float* const* W0, const float* const* W1, float* area0, long sArea, long R, hipStream_t stream) {
+int hp_conv_split_prep(int n, const float* const* W0, const float* const* W1, float* area0, long sArea, long R, int fmt, hipStream_t stream) {
     PrepParams p{};
     for (int l = 0; l < 4; ++l) {
         p.W[l] = W0[l];
@@ -453,6 +456,8 @@ int hp_conv_split_prep(int n, const float* const* W0, const float* const* W1, fl
     p.wexp = reinterpret_cast<int*>(area0 + HP_CS_WEXP_OFF);
     p.hl = reinterpret_cast<_Float16*>(area0 + HP_CS_HI_OFF);
     p.sArea = sArea;
+    p.fmt = reinterpret_cast<int*>(area0 + hp_conv_pp_fmt_offset(R));
+    p.fmt_value = fmt;
     hipLaunchKernelGGL(conv_split_prep_kernel, dim3(kRows[4] / 4, n), dim3(256), 0, stream, p);
     HP_RETURN_LAST_ERROR();
 }
@@ -503,6 +508,13 @@ HP_API int hp_gemm_f16x2_prepare(long M, int N, int K, const float* X, const flo
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)((M + 127) / 128)), dim3(256), 0, stream, X, M, K, reinterpret_cast<unsigned*>(ws));
     hipLaunchKernelGGL(split_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, W, N, K, reinterpret_cast<_Float16*>(ws + tp + N),
                        reinterpret_cast<int*>(ws + tp));
+    HP_RETURN_LAST_ERROR();
+}
+
+// W (N, K) fp32 -> P-format rows + per-row exponents (conv_pp.hip's stand-alone primitive shares this launch)
+int hp_split_rows_launch(const float* W, int N, int K, float* hl, float* wexp, hipStream_t stream) {
+    hipLaunchKernelGGL(split_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, W, N, K, reinterpret_cast<_Float16*>(hl),
+                       reinterpret_cast<int*>(wexp));
     HP_RETURN_LAST_ERROR();
 }
 

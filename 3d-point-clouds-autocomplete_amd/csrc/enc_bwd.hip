@@ -32,6 +32,7 @@
 //  * equal tasks: with 8 + 2 + 1 workgroups per range of unequal cost the dW launch took 2.1x its MFMA time.
 #include "hp_common.h"
 #include "hp_enc_bwd.h"
+#include "hp_conv_split.h"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -60,6 +61,26 @@ __device__ __forceinline__ float4 f4fma(float g, const float4& w, const float4& 
 }
 __device__ __forceinline__ float4 f4mask(const float4& h, const float4& v) {
     return make_float4(h.x > 0.f ? v.x : 0.f, h.y > 0.f ? v.y : 0.f, h.z > 0.f ? v.z : 0.f, h.w > 0.f ? v.w : 0.f);
+}
+
+// ---- the forward's activations: fp32 rows, or P-format lines (conv_pp.hip) — (hi + lo) * 2^-e is exact in fp32 ----------------
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float pexp_unscale(int e) { return __uint_as_float((unsigned)(127 - e) << 23); }   // 2^-e, e in [-100, 54]
+// channels c .. c+3 (c % 4 == 0) of row `row` of h_L (C channels)
+template <int C, int L>
+__device__ __forceinline__ float4 act4(const HpEncBwdSide& s, bool pfmt, long row, int c) {
+    if (!pfmt) return *reinterpret_cast<const float4*>(s.h[L] + row * C + c);
+    const unsigned char* line = reinterpret_cast<const unsigned char*>(s.h[L]) + row * (C * 4L) + (c >> 5) * 128 + (c & 31) * 2;
+    const f16x4 hi = *reinterpret_cast<const f16x4*>(line), lo = *reinterpret_cast<const f16x4*>(line + 64);
+    const float us = pexp_unscale(L == 4 ? s.pexp[4][(row >> 7) * 2 + (c >> 8)] : s.pexp[L][row >> 7]);
+    return make_float4(((float)hi[0] + (float)lo[0]) * us, ((float)hi[1] + (float)lo[1]) * us, ((float)hi[2] + (float)lo[2]) * us,
+                       ((float)hi[3] + (float)lo[3]) * us);
+}
+template <int C, int L>
+__device__ __forceinline__ float act1(const HpEncBwdSide& s, bool pfmt, long row, int c) {
+    if (!pfmt) return s.h[L][row * C + c];
+    const _Float16* line = reinterpret_cast<const _Float16*>(reinterpret_cast<const unsigned char*>(s.h[L]) + row * (C * 4L) + (c >> 5) * 128);
+    return ((float)line[c & 31] + (float)line[32 + (c & 31)]) * pexp_unscale(s.pexp[L][row >> 7]);
 }
 
 #ifndef HP_EB_GWG
@@ -157,6 +178,7 @@ __global__ __launch_bounds__(256) void enc_bwd_gather_kernel(const HpEncBwdArgs 
     const HpEncBwdSide& s = a.e[z];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     Stamp stamp(a.prof ? a.prof + (long)id * 4 : nullptr, tid);
+    const bool pfmt = *s.fmt == HP_PP_FMT_P;      // (uniform: the format the forward left h1..h4 in)
     if (rest >= kGatherRowWgs) {      // (the uniform 11-us channel tasks behind the row tasks, whose length varies)
         const int c = rest - kGatherRowWgs;
         stamp.type = 1;
@@ -174,10 +196,9 @@ __global__ __launch_bounds__(256) void enc_bwd_gather_kernel(const HpEncBwdArgs 
             __syncthreads();
             if (tid == 0)
                 for (int b = 0; b < nb; ++b) bsum += sdg[b];
-            const float* hb = s.h[4] + (long)c0 * a.Np * 512 + 4 * q;
 #pragma unroll 8
             for (int b = g; b < nb; b += 2) {
-                const float4 hv = *reinterpret_cast<const float4*>(hb + ((long)b * a.Np + sarg[b]) * 512);
+                const float4 hv = act4<512, 4>(s, pfmt, (long)(c0 + b) * a.Np + sarg[b], 4 * q);
                 acc = f4fma(sdg[b], hv, acc);
             }
         }
@@ -209,8 +230,8 @@ __global__ __launch_bounds__(256) void enc_bwd_gather_kernel(const HpEncBwdArgs 
             continue;
         }
         const int i0 = s.crit.start[(long)b * 513 + u], i1 = s.crit.start[(long)b * 513 + u + 1];
-        const float* hr = s.h[4] + ((long)b * a.Np + s.crit.pt[(long)b * 512 + u]) * 512 + 4 * lane;
-        const float4 h0 = *reinterpret_cast<const float4*>(hr), h1 = *reinterpret_cast<const float4*>(hr + 256);
+        const long hrow = (long)b * a.Np + s.crit.pt[(long)b * 512 + u];
+        const float4 h0 = act4<512, 4>(s, pfmt, hrow, 4 * lane), h1 = act4<512, 4>(s, pfmt, hrow, 256 + 4 * lane);
         float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
         constexpr int EB = HP_EB_GEB;
         for (int i = i0; i < i1; i += EB) {      // (uniform per wave)
@@ -380,6 +401,7 @@ __global__ __launch_bounds__(kChainThreads, 2) void enc_bwd_chain_kernel(const H
         if (b < 0) return;
     }
     const HpEncBwdSide& s = a.e[z];
+    const bool pfmt = *s.fmt == HP_PP_FMT_P;
     const long row0 = (long)b * 512 + q * kRows;          // first row of the block in the delta / hc arrays
     const int u0 = q * kRows;
     long long* prof = a.prof ? a.prof + (long)blockIdx.x * 10 : nullptr;
@@ -437,7 +459,7 @@ __global__ __launch_bounds__(kChainThreads, 2) void enc_bwd_chain_kernel(const H
         chain_mfma4<256, 256, LD3>(As, s.W[3], 0, 256, 128 * w, r, h, acc);
         float4 hm[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) hm[e] = *reinterpret_cast<const float4*>(s.h[3] + (long)rsrc[e] * 256 + 128 * w + 4 * r);
+        for (int e = 0; e < 16; ++e) hm[e] = act4<256, 3>(s, pfmt, rsrc[e], 128 * w + 4 * r);
         __syncthreads();   // both waves are done reading delta4
         HP_STAMP(2);
 #pragma unroll
@@ -465,7 +487,7 @@ __global__ __launch_bounds__(kChainThreads, 2) void enc_bwd_chain_kernel(const H
         float4 hm[16];
         if (w == 0) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) hm[e] = *reinterpret_cast<const float4*>(s.h[2] + (long)rsrc[e] * 128 + 4 * r);
+            for (int e = 0; e < 16; ++e) hm[e] = act4<128, 2>(s, pfmt, rsrc[e], 4 * r);
         }
         __syncthreads();
         float* scr = As + kRows * LD2;   // behind delta2: 4 tiles x 16 x 64 floats
@@ -496,7 +518,7 @@ __global__ __launch_bounds__(kChainThreads, 2) void enc_bwd_chain_kernel(const H
     {
         float hm[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) hm[e] = s.h[1][(long)rsrc[e] * 64 + 32 * w + r];
+        for (int e = 0; e < 16; ++e) hm[e] = act1<64, 1>(s, pfmt, rsrc[e], 32 * w + r);
         f32x16 acc[1];
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[0][e] = 0.f;

@@ -26,7 +26,10 @@ struct HpEncBwdSide {
     const int* argidx;       /* (B, 512) */
     const float* dg;         /* (B, 512)  d/d (max-pooled features), from the tail's backward */
     const float* W[5];       /* conv weights, W[l-1] = layer l: (kEnc[l], kEnc[l-1]) row-major */
-    const float* h[5];       /* h[l] = the forward's per-point activations of layer l (l = 1..4), (B*Np, kEnc[l]) */
+    const float* h[5];       /* h[l] = the forward's per-point activations of layer l (l = 1..4), (B*Np, kEnc[l]): fp32, or — when
+                                *fmt == HP_PP_FMT_P — P-format lines [hi 32 | lo 32] f16 with block exponents pexp[l] (conv_pp.hip) */
+    const int* fmt;          /* the forward workspace's format word */
+    const int* pexp[5];      /* pexp[l][(row >> 7) * ncb + block]: ncb = 1 for l = 1..3, 2 (256-channel blocks) for l = 4 */
     /* VAE head (prep kernel): d mu = gz + gmu ; d lv = (gz*eps + gexplv) * exp(lv) */
     const float *eps, *lv, *gout, *gmu, *gexplv;
     float *dmu, *dlv;

@@ -614,10 +614,23 @@ int encoder_forward_impl(int B, int Np, int out_size, int n, const HpEncoderIO* 
     // else the fp32 MFMA GEMMs.
     const bool split = hp_conv_split_enabled();
     float* area = h[5] + R * 512;
+    // Round 4: with whole 128-row tiles per cloud the activations are stored already split ("P-format", conv_pp.hip) and both
+    // operands of layers 2..5 are DMA-staged; a word in the split area tells the backward's readers which format h1..h4 hold.
+    const bool presplit = split && hp_conv_presplit_enabled() && Np % 128 == 0;
     if (split) {
         const float* W0[4] = {e0.w->conv_w[1], e0.w->conv_w[2], e0.w->conv_w[3], e0.w->conv_w[4]};
         const float* W1[4] = {e1.w->conv_w[1], e1.w->conv_w[2], e1.w->conv_w[3], e1.w->conv_w[4]};
-        TRY(hp_conv_split_prep(n, W0, W1, area, sWs, R, stream));
+        TRY(hp_conv_split_prep(n, W0, W1, area, sWs, R, presplit ? HP_PP_FMT_P : HP_PP_FMT_F32, stream));
+    } else {
+        TRY(hp_conv_pp_mark(n, area, sWs, R, HP_PP_FMT_F32, stream));
+    }
+    if (presplit) {
+        TRY(hp_conv_pp_layer1(n, e0.x, dz(e0.x, e1.x), e0.w->conv_w[0], dz(e0.w->conv_w[0], e1.w->conv_w[0]), e0.w->conv_b[0],
+                              dz(e0.w->conv_b[0], e1.w->conv_b[0]), h[1], area, sWs, R, stream));
+        for (int l = 2; l <= 4; ++l)
+            TRY(hp_conv_pp_layer(l, n, h[l - 1], e0.w->conv_b[l - 1], dz(e0.w->conv_b[l - 1], e1.w->conv_b[l - 1]), h[l], area, sWs, R,
+                                 nullptr, nullptr, 0, stream));
+    } else if (split) {
         TRY(hp_conv_split_layer1(n, e0.x, dz(e0.x, e1.x), e0.w->conv_w[0], dz(e0.w->conv_w[0], e1.w->conv_w[0]), e0.w->conv_b[0],
                                  dz(e0.w->conv_b[0], e1.w->conv_b[0]), h[1], sWs, area, sWs, R, stream));
         for (int l = 2; l <= 4; ++l)
@@ -651,7 +664,9 @@ int encoder_forward_impl(int B, int Np, int out_size, int n, const HpEncoderIO* 
         d5.cmax = h[5];
         d5.cidx = reinterpret_cast<int*>(h[5] + tiles * 512);
         if (R * 512 - up4(2 * tiles * 512) >= 4L * 64 * 512 + 8L * 64 * out_size) tail_off = up4(2 * tiles * 512);
-        if (split)
+        if (presplit)
+            TRY(hp_conv_pp_layer(5, n, h[4], d5.bias, d5.sBiasz, nullptr, area, sWs, R, d5.cmax, d5.cidx, Np, stream));
+        else if (split)
             TRY(hp_conv_split_layer(5, n, h[4], sWs, d5.bias, d5.sBiasz, nullptr, sWs, area, sWs, R, 0, 1, d5.cmax, d5.cidx, Np, stream));
         else
             TRY(hp_gemm_f32(&d5, stream));
@@ -715,6 +730,13 @@ HP_API int hp_encoder_forward(int B, int Np, const float* x, const HpEncoderWeig
 // Both encoders of a HyperPocket step in one call: io[0], io[1] as hp_encoder_forward's arguments; same B, Np, out_size.
 // The two workspaces (hp_encoder_forward_workspace_floats each) may lie anywhere; results are those of two
 // hp_encoder_forward calls.
+// h1..h4 inside a forward workspace as fp32 rows (B*Np, 64 | 128 | 256 | 512), whatever format the forward left them in
+// (round 4's P-format is converted in place; otherwise nothing happens).  What the layered backward does first; the tests' view.
+HP_API int hp_encoder_workspace_to_f32(int B, int Np, float* ws, hipStream_t stream) {
+    HP_CHECK_ARG(B > 0 && Np > 0 && ws);
+    return hp_conv_pp_unpack_ws(ws, (long)B * Np, stream);
+}
+
 HP_API int hp_encoder_forward_pair(int B, int Np, int out_size, const HpEncoderIO* io, hipStream_t stream) {
     HP_CHECK_ARG(B > 0 && Np > 0 && out_size > 0 && io && encoder_io_ok(io[0]) && encoder_io_ok(io[1]));
     HP_CHECK_ARG(B <= 32767 && (long)B * Np < (1L << 31));
@@ -847,6 +869,9 @@ int encoder_backward_layered(int B, int Np, int out_size, const HpEncoderBwdIO& 
     float** hc = L.hc;
     float** dl = L.dl;
     float *dmu = L.dmu, *dlv = L.dlv, *dfc = L.dfc, *dg = L.dg;
+    // (the layered launches read h1..h4 as fp32 rows: a forward that left them in P-format is converted in place first — a
+    //  no-op when the workspace's format word says fp32)
+    if (e.fwd_ws) TRY(hp_conv_pp_unpack_ws(const_cast<float*>(e.fwd_ws), (long)B * Np, stream));
     TRY(enc_critical_rows(B, Np, e.x, w, out_size, e.argidx, e.fwd_ws, e.ws, dedup, stream));
 
     // ---- heads (model/encoder.py:46-53)
@@ -920,6 +945,13 @@ int encoder_backward_fused(int B, int Np, int out_size, int n, const HpEncoderBw
         s.h[0] = nullptr;
         s.h[1] = e.fwd_ws;
         for (int l = 2; l <= 4; ++l) s.h[l] = s.h[l - 1] + R * kEnc[l - 1];
+        {   // the split area behind h5's slot: the workspace's format word and the P-format block exponents (conv_pp.hip)
+            const float* area = e.fwd_ws + R * (64 + 128 + 256 + 512 + 512);
+            const long tp = hp_conv_split_tiles_pad(R);
+            s.fmt = reinterpret_cast<const int*>(area + hp_conv_pp_fmt_offset(R));
+            s.pexp[0] = nullptr;
+            for (int l = 1; l <= 4; ++l) s.pexp[l] = reinterpret_cast<const int*>(area + hp_conv_pp_exp_offset(l, tp));
+        }
         for (int l = 0; l < 5; ++l) {
             s.W[l] = e.w->conv_w[l];
             s.gW[l] = e.gr->conv_w[l];

@@ -221,6 +221,24 @@ typedef struct HpEncoderIO {
                    encoders of a pair can so write the halves of one (B, 2*out) latent [z | real mu] directly */
 } HpEncoderIO;
 int hp_encoder_forward_pair(int B, int Np, int out_size, const HpEncoderIO* io /* [2] */, hpStream_t stream);
+/* Layout of the forward workspace: per-point activations h1..h4 (B*Np rows of 64 | 128 | 256 | 512 channels, 4 bytes per value), the
+ * slot of h5 (per-tile maxima, tail slabs), then the split area (weight pieces, exponents).  Since round 4 the fast path (whole
+ * 128-point tiles per cloud) stores h1..h4 as f16 piece pairs with block exponents ("P-format", csrc/conv_pp.hip) — the operand
+ * format of the next layer's matrix-core launch — and says so in a word of the split area; hp_encoder_backward* read either
+ * format.  hp_encoder_workspace_to_f32 converts such a workspace to plain fp32 rows in place (idempotent). */
+int hp_encoder_workspace_to_f32(int B, int Np, float* ws, hpStream_t stream);
+/* [test hook: process-wide, not thread-safe — see the header comment] 0: the conv stack takes fp32 activations again (round 3's
+ * kernels, csrc/conv_split.hip; also: environment HP_CONV_PRESPLIT=0).  Returns the previous setting. */
+int hp_conv_presplit_set(int on);
+/* The P-format GEMM as a stand-alone primitive (bench.py's roofline leg, tests): C = act(X W^T + b), X (M,K), W (N,K) fp32, N % 128
+ * == 0, K % 32 == 0, K <= 512.  prepare packs X (one exponent per 128 rows x xcb channels) and W into ws
+ * (hp_gemm_pp_workspace_floats floats); run is the matrix-core launch alone: mode 0 stores C in P-format inside ws
+ * (hp_gemm_pp_unpack -> fp32), mode 1 forms per-128-row-tile column maxima of X W^T + b and their rows (hp_gemm_pp_partials). */
+long hp_gemm_pp_workspace_floats(long M, int N, int K);
+int hp_gemm_pp_prepare(long M, int N, int K, int xcb, const float* X, const float* W, float* ws, hpStream_t stream);
+int hp_gemm_pp_run(long M, int N, int K, int xcb, const float* bias, int relu, int mode, int group_rows, float* ws, hpStream_t stream);
+int hp_gemm_pp_unpack(long M, int N, int K, const float* ws, float* C, hpStream_t stream);
+int hp_gemm_pp_partials(long M, int N, int K, const float* ws, float* cmax, int* cidx, hpStream_t stream);
 /* Gradients of every encoder parameter (autograd of the above).  grad_out = d/dz (VAE) or d/dmu (plain);
  * grad_mu / grad_explv = direct gradients on the VAE outputs (may be NULL).  Only the 512 arg-max points of a
  * cloud carry gradient below the max-pool: their activations are copied out of fwd_ws (the workspace
