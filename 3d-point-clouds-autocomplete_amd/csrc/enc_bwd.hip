@@ -64,23 +64,22 @@ __device__ __forceinline__ float4 f4mask(const float4& h, const float4& v) {
 }
 
 // ---- the forward's activations: fp32 rows, or P-format lines (conv_pp.hip) — (hi + lo) * 2^-e is exact in fp32 ----------------
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ float pexp_unscale(int e) { return __uint_as_float((unsigned)(127 - e) << 23); }   // 2^-e, e in [-100, 54]
-// channels c .. c+3 (c % 4 == 0) of row `row` of h_L (C channels)
-template <int C, int L>
-__device__ __forceinline__ float4 act4(const HpEncBwdSide& s, bool pfmt, long row, int c) {
-    if (!pfmt) return *reinterpret_cast<const float4*>(s.h[L] + row * C + c);
-    const unsigned char* line = reinterpret_cast<const unsigned char*>(s.h[L]) + row * (C * 4L) + (c >> 5) * 128 + (c & 31) * 2;
-    const f16x4 hi = *reinterpret_cast<const f16x4*>(line), lo = *reinterpret_cast<const f16x4*>(line + 64);
-    const float us = pexp_unscale(L == 4 ? s.pexp[4][(row >> 7) * 2 + (c >> 8)] : s.pexp[L][row >> 7]);
-    return make_float4(((float)hi[0] + (float)lo[0]) * us, ((float)hi[1] + (float)lo[1]) * us, ((float)hi[2] + (float)lo[2]) * us,
-                       ((float)hi[3] + (float)lo[3]) * us);
-}
-template <int C, int L>
-__device__ __forceinline__ float act1(const HpEncBwdSide& s, bool pfmt, long row, int c) {
-    if (!pfmt) return s.h[L][row * C + c];
-    const _Float16* line = reinterpret_cast<const _Float16*>(reinterpret_cast<const unsigned char*>(s.h[L]) + row * (C * 4L) + (c >> 5) * 128);
-    return ((float)line[c & 31] + (float)line[32 + (c & 31)]) * pexp_unscale(s.pexp[L][row >> 7]);
+// channels c8 .. c8+7 (c8 % 8 == 0) of a row of C channels starting at byte address `rowp`: two float4 (fp32 rows), or one
+// 16-byte chunk of the hi pieces + the matching chunk of the lo pieces, unscaled by `us` = 2^-e of the row's block
+__device__ __forceinline__ void act8(const unsigned char* rowp, bool pfmt, int c8, float us, float4& a, float4& b) {
+    if (!pfmt) {
+        a = *reinterpret_cast<const float4*>(rowp + c8 * 4);
+        b = *reinterpret_cast<const float4*>(rowp + c8 * 4 + 16);
+        return;
+    }
+    const unsigned char* line = rowp + (c8 >> 5) * 128 + (c8 & 31) * 2;
+    const f16x8 hi = *reinterpret_cast<const f16x8*>(line), lo = *reinterpret_cast<const f16x8*>(line + 64);
+    a = make_float4(((float)hi[0] + (float)lo[0]) * us, ((float)hi[1] + (float)lo[1]) * us, ((float)hi[2] + (float)lo[2]) * us,
+                    ((float)hi[3] + (float)lo[3]) * us);
+    b = make_float4(((float)hi[4] + (float)lo[4]) * us, ((float)hi[5] + (float)lo[5]) * us, ((float)hi[6] + (float)lo[6]) * us,
+                    ((float)hi[7] + (float)lo[7]) * us);
 }
 
 #ifndef HP_EB_GWG
@@ -172,49 +171,80 @@ __global__ __launch_bounds__(512) void enc_bwd_prep_kernel(const HpEncBwdArgs a)
 __global__ __launch_bounds__(256) void enc_bwd_gather_kernel(const HpEncBwdArgs a) {
     __shared__ int sarg[256];
     __shared__ float sdg[256];
-    __shared__ float4 red[128];
+    __shared__ float sus[256][2];
+    __shared__ float4 red[3][64][2];
     const int id = blockIdx.x;
     const int z = a.n == 2 ? (id & 1) : 0, rest = a.n == 2 ? (id >> 1) : id;
     const HpEncBwdSide& s = a.e[z];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     Stamp stamp(a.prof ? a.prof + (long)id * 4 : nullptr, tid);
     const bool pfmt = *s.fmt == HP_PP_FMT_P;      // (uniform: the format the forward left h1..h4 in)
+    const unsigned char* h4b = reinterpret_cast<const unsigned char*>(s.h[4]);
     if (rest >= kGatherRowWgs) {      // (the uniform 11-us channel tasks behind the row tasks, whose length varies)
+        // dW5[c,:] = sum_b dg[b,c] * h4[b, argmax[b,c], :], db5[c] = sum_b dg[b,c]: lane q owns channels 8q..8q+7 of a row (one
+        // 16-byte chunk of hi pieces + one of lo pieces, or two float4), wave g takes the clouds b = g mod 4; the (argmax, dg,
+        // unscale) triples of 256 clouds at a time go through LDS so that the row loads are one round trip deep; the four
+        // cloud classes are added in the order 0..3.
         const int c = rest - kGatherRowWgs;
         stamp.type = 1;
-        const int q = tid & 127, g = tid >> 7;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int q = lane, g = w;
+        float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
         float bsum = 0.f;
         for (int c0 = 0; c0 < a.B; c0 += 256) {
             const int nb = min(256, a.B - c0);
             __syncthreads();
             if (tid < nb) {
                 const long row = (long)(c0 + tid) * 512 + c;
-                sarg[tid] = s.argidx[row];
+                const int arg = s.argidx[row];
+                sarg[tid] = arg;
                 sdg[tid] = s.dg[row];
+                if (pfmt) {
+                    const long hrow = (long)(c0 + tid) * a.Np + arg;
+                    sus[tid][0] = pexp_unscale(s.pexp[4][(hrow >> 7) * 2]);
+                    sus[tid][1] = pexp_unscale(s.pexp[4][(hrow >> 7) * 2 + 1]);
+                }
             }
             __syncthreads();
             if (tid == 0)
                 for (int b = 0; b < nb; ++b) bsum += sdg[b];
-#pragma unroll 8
-            for (int b = g; b < nb; b += 2) {
-                const float4 hv = act4<512, 4>(s, pfmt, (long)(c0 + b) * a.Np + sarg[b], 4 * q);
-                acc = f4fma(sdg[b], hv, acc);
+#pragma unroll 4
+            for (int b = g; b < nb; b += 4) {
+                float4 h0, h1;
+                act8(h4b + ((long)(c0 + b) * a.Np + sarg[b]) * 2048, pfmt, 8 * q, pfmt ? sus[b][q >> 5] : 1.f, h0, h1);
+                acc0 = f4fma(sdg[b], h0, acc0);
+                acc1 = f4fma(sdg[b], h1, acc1);
             }
         }
         if (tid == 0 && s.gb[4]) s.gb[4][c] = bsum;
-        if (g) red[q] = acc;
+        if (g) {
+            red[g - 1][q][0] = acc0;
+            red[g - 1][q][1] = acc1;
+        }
         __syncthreads();
         if (g == 0) {
-            const float4 o = red[q];
-            *reinterpret_cast<float4*>(s.gW[4] + (long)c * 512 + 4 * q) = make_float4(acc.x + o.x, acc.y + o.y, acc.z + o.z, acc.w + o.w);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float4 o0 = red[k][q][0], o1 = red[k][q][1];
+                acc0 = make_float4(acc0.x + o0.x, acc0.y + o0.y, acc0.z + o0.z, acc0.w + o0.w);
+                acc1 = make_float4(acc1.x + o1.x, acc1.y + o1.y, acc1.z + o1.z, acc1.w + o1.w);
+            }
+            *reinterpret_cast<float4*>(s.gW[4] + (long)c * 512 + 8 * q) = acc0;
+            *reinterpret_cast<float4*>(s.gW[4] + (long)c * 512 + 8 * q + 4) = acc1;
         }
         return;
     }
     // row workgroups are PERSISTENT: kGatherRowWgs of them per encoder stride over the B*128 groups of four slots (a grid
-    // of one workgroup per group — 16K workgroups, two thirds of them dead — was bound by workgroup dispatch: ~50 us)
+    // of one workgroup per group — 16K workgroups, two thirds of them dead — was bound by workgroup dispatch: ~50 us).
+    // ONE WAVE per row (cloud b, slot u), a lane owns the 8 columns [8 lane, +8) of the 512:
+    //   delta4[row] = (h4[row] > 0) * sum over the row's channels, ascending, of dg[b,c] * W5[c,:]
+    // and the row's activations below (h3: lanes 0..31, h2: 32..47, h1: 48..55) are copied — out of the forward's arrays,
+    // whatever their format — into the compact fp32 rows hc[1..3] the chain and dW launches read.  Rows in [cnt, ru32(cnt))
+    // are written as zeros (the matrix-core launches run on whole 32-row blocks).
     stamp.type = 2;
-    const float* w5 = s.W[4] + 4 * lane;
+    const float* w5 = s.W[4] + 8 * lane;
+    // which of h3 / h2 / h1 this lane copies, and its 8 channels there
+    const int hl = lane < 32 ? 3 : (lane < 48 ? 2 : (lane < 56 ? 1 : 0));
+    const int hC = hl == 3 ? 256 : (hl == 2 ? 128 : 64), hc8 = hl == 3 ? 8 * lane : (hl == 2 ? 8 * (lane - 32) : 8 * (lane - 48));
     for (int rg = rest; rg < a.B * 128; rg += kGatherRowWgs) {
         // group rg = (slot group q = rg / B, cloud b = rg % B): a workgroup's groups are then spread over the slot range —
         // only the first ~cnt/4 groups of a cloud are live — instead of all low or all high
@@ -223,15 +253,29 @@ __global__ __launch_bounds__(256) void enc_bwd_gather_kernel(const HpEncBwdArgs 
         if (u >= ru32(cnt)) continue;
         const int* chan = s.crit.chan + (long)b * 512;
         const float* dgb = s.dg + (long)b * 512;
-        float* dst = s.d[4] + ((long)b * 512 + u) * 512 + 4 * lane;
+        const long crow = (long)b * 512 + u;
+        float* dst = s.d[4] + crow * 512 + 8 * lane;
+        float* hdst = hl ? s.hc[hl] + crow * hC + hc8 : nullptr;
         if (u >= cnt) {
-            *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(dst + 256) = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(dst) = zero;
+            *reinterpret_cast<float4*>(dst + 4) = zero;
+            if (hl) {
+                *reinterpret_cast<float4*>(hdst) = zero;
+                *reinterpret_cast<float4*>(hdst + 4) = zero;
+            }
             continue;
         }
         const int i0 = s.crit.start[(long)b * 513 + u], i1 = s.crit.start[(long)b * 513 + u + 1];
         const long hrow = (long)b * a.Np + s.crit.pt[(long)b * 512 + u];
-        const float4 h0 = act4<512, 4>(s, pfmt, hrow, 4 * lane), h1 = act4<512, 4>(s, pfmt, hrow, 256 + 4 * lane);
+        float us4 = 1.f, usl = 1.f;
+        if (pfmt) {
+            us4 = pexp_unscale(s.pexp[4][(hrow >> 7) * 2 + (lane >> 5)]);
+            if (hl) usl = pexp_unscale(s.pexp[hl][hrow >> 7]);
+        }
+        float4 h0, h1, g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
+        act8(h4b + hrow * 2048, pfmt, 8 * lane, us4, h0, h1);
+        if (hl) act8(reinterpret_cast<const unsigned char*>(s.h[hl]) + hrow * (hC * 4L), pfmt, hc8, usl, g0, g1);
         float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
         constexpr int EB = HP_EB_GEB;
         for (int i = i0; i < i1; i += EB) {      // (uniform per wave)
@@ -244,7 +288,7 @@ __global__ __launch_bounds__(256) void enc_bwd_gather_kernel(const HpEncBwdArgs 
             for (int k = 0; k < EB; ++k) {
                 g[k] = dgb[ch[k]];
                 w0[k] = *reinterpret_cast<const float4*>(w5 + (long)ch[k] * 512);
-                w1[k] = *reinterpret_cast<const float4*>(w5 + (long)ch[k] * 512 + 256);
+                w1[k] = *reinterpret_cast<const float4*>(w5 + (long)ch[k] * 512 + 4);
             }
 #pragma unroll
             for (int k = 0; k < EB; ++k)
@@ -254,7 +298,11 @@ __global__ __launch_bounds__(256) void enc_bwd_gather_kernel(const HpEncBwdArgs 
                 }
         }
         *reinterpret_cast<float4*>(dst) = f4mask(h0, a0);
-        *reinterpret_cast<float4*>(dst + 256) = f4mask(h1, a1);
+        *reinterpret_cast<float4*>(dst + 4) = f4mask(h1, a1);
+        if (hl) {
+            *reinterpret_cast<float4*>(hdst) = g0;
+            *reinterpret_cast<float4*>(hdst + 4) = g1;
+        }
     }
 }
 
@@ -370,7 +418,6 @@ constexpr int kChainThreads = 128;
 
 __global__ __launch_bounds__(kChainThreads, 2) void enc_bwd_chain_kernel(const HpEncBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float As[kRows * LD3];
-    __shared__ int srow[kRows];
     __shared__ unsigned svalid;
     // block id -> (encoder, cloud, 32-row block): the live blocks of all clouds of both encoders are the FIRST ids, so that
     // consecutive ids — which the dispatcher deals round-robin over the 8 XCDs — are all live.  Every wave finds its block
@@ -401,7 +448,6 @@ __global__ __launch_bounds__(kChainThreads, 2) void enc_bwd_chain_kernel(const H
         if (b < 0) return;
     }
     const HpEncBwdSide& s = a.e[z];
-    const bool pfmt = *s.fmt == HP_PP_FMT_P;
     const long row0 = (long)b * 512 + q * kRows;          // first row of the block in the delta / hc arrays
     const int u0 = q * kRows;
     long long* prof = a.prof ? a.prof + (long)blockIdx.x * 10 : nullptr;
@@ -424,10 +470,7 @@ __global__ __launch_bounds__(kChainThreads, 2) void enc_bwd_chain_kernel(const H
         }
     };
     stage4(0);
-    if (tid < kRows) {   // the rows' sources in the forward's arrays (a valid row either way)
-        srow[tid] = (int)((long)b * a.Np + (u0 + tid < cnt ? s.crit.pt[(long)b * 512 + u0 + tid] : 0));
-        if (tid == 0) svalid = cnt - u0 >= 32 ? 0xffffffffu : ((1u << (cnt - u0)) - 1u);
-    }
+    if (tid == 0) svalid = cnt - u0 >= 32 ? 0xffffffffu : ((1u << (cnt - u0)) - 1u);
     if (tid < kRows * 3) {   // the rows' coordinates (dW1's operand)
         const int xr = tid / 3, xc = tid - xr * 3;
         s.hc[0][(row0 + xr) * 3 + xc] = u0 + xr < cnt ? s.x[((long)b * a.Np + s.crit.pt[(long)b * 512 + u0 + xr]) * 3 + xc] : 0.f;
@@ -435,14 +478,11 @@ __global__ __launch_bounds__(kChainThreads, 2) void enc_bwd_chain_kernel(const H
     __syncthreads();
     HP_STAMP(1);
 
-    // per lane: the 16 rows of its accumulator registers in the forward's arrays; bit e of vm: the row exists
-    int rsrc[16];
+    // per lane: bit e of vm: the row of accumulator register e exists (the rows' activations h1..h3 were copied into the compact
+    // fp32 rows hc[1..3] by the gather launch, zeros past a cloud's count)
     unsigned vm = 0;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        rsrc[e] = srow[drow(e, h)];
-        vm |= ((svalid >> drow(e, h)) & 1u) << e;
-    }
+    for (int e = 0; e < 16; ++e) vm |= ((svalid >> drow(e, h)) & 1u) << e;
 
     // ---- delta3 = (delta4 W4) * (h3 > 0)      K = 512 in two staged halves, N = 256: wave w takes the 128 columns
     //      [128 w, +128) as four interleaved tiles
@@ -459,7 +499,7 @@ __global__ __launch_bounds__(kChainThreads, 2) void enc_bwd_chain_kernel(const H
         chain_mfma4<256, 256, LD3>(As, s.W[3], 0, 256, 128 * w, r, h, acc);
         float4 hm[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) hm[e] = act4<256, 3>(s, pfmt, rsrc[e], 128 * w + 4 * r);
+        for (int e = 0; e < 16; ++e) hm[e] = *reinterpret_cast<const float4*>(s.hc[3] + (row0 + drow(e, h)) * 256 + 128 * w + 4 * r);
         __syncthreads();   // both waves are done reading delta4
         HP_STAMP(2);
 #pragma unroll
@@ -469,7 +509,6 @@ __global__ __launch_bounds__(kChainThreads, 2) void enc_bwd_chain_kernel(const H
             const float4 v = f4mask(hv, make_float4(acc[0][e], acc[1][e], acc[2][e], acc[3][e]));
             *reinterpret_cast<float4*>(&As[row * LD3 + col]) = v;
             *reinterpret_cast<float4*>(s.d[3] + (row0 + row) * 256 + col) = v;
-            *reinterpret_cast<float4*>(s.hc[3] + (row0 + row) * 256 + col) = hv;
         }
     }
     __syncthreads();
@@ -487,7 +526,7 @@ __global__ __launch_bounds__(kChainThreads, 2) void enc_bwd_chain_kernel(const H
         float4 hm[16];
         if (w == 0) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) hm[e] = act4<128, 2>(s, pfmt, rsrc[e], 4 * r);
+            for (int e = 0; e < 16; ++e) hm[e] = *reinterpret_cast<const float4*>(s.hc[2] + (row0 + drow(e, h)) * 128 + 4 * r);
         }
         __syncthreads();
         float* scr = As + kRows * LD2;   // behind delta2: 4 tiles x 16 x 64 floats
@@ -507,7 +546,6 @@ __global__ __launch_bounds__(kChainThreads, 2) void enc_bwd_chain_kernel(const H
                                                         acc[2][e] + scr[(2 * 16 + e) * 64 + lane], acc[3][e] + scr[(3 * 16 + e) * 64 + lane]));
                 *reinterpret_cast<float4*>(&As[row * LD2 + col]) = v;
                 *reinterpret_cast<float4*>(s.d[2] + (row0 + row) * 128 + col) = v;
-                *reinterpret_cast<float4*>(s.hc[2] + (row0 + row) * 128 + col) = hv;
             }
         }
     }
@@ -518,7 +556,7 @@ __global__ __launch_bounds__(kChainThreads, 2) void enc_bwd_chain_kernel(const H
     {
         float hm[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) hm[e] = act1<64, 1>(s, pfmt, rsrc[e], 32 * w + r);
+        for (int e = 0; e < 16; ++e) hm[e] = s.hc[1][(row0 + drow(e, h)) * 64 + 32 * w + r];
         f32x16 acc[1];
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[0][e] = 0.f;
@@ -528,7 +566,6 @@ __global__ __launch_bounds__(kChainThreads, 2) void enc_bwd_chain_kernel(const H
             const int row = drow(e, h), col = 32 * w + r;
             const bool ok = (vm >> e) & 1u;
             s.d[1][(row0 + row) * 64 + col] = (ok && hm[e] > 0.f) ? acc[0][e] : 0.f;
-            s.hc[1][(row0 + row) * 64 + col] = ok ? hm[e] : 0.f;
         }
     }
     HP_STAMP(5);
