@@ -34,6 +34,7 @@
 #include "hp_conv_split.h"
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -59,18 +60,32 @@ __device__ __forceinline__ float pow2f(int e) {
 }
 __device__ __forceinline__ int block_exp(float m) { return min(kTarget - frexp_exp(__float_as_uint(m)), kExpMax); }
 __device__ __forceinline__ unsigned pack2(_Float16 a, _Float16 b) { return __builtin_bit_cast(unsigned, f16x2{a, b}); }
+// the lo pieces of two values whose hi pieces are packed in `hpk`: lo = f16(x - f32(hi)) in ONE instruction each (v_fma_mix
+// takes the f16 operand as it is; through C++ the compiler emits cvt + sub + cvt: 3 of the ~9 vector instructions per output
+// element of a store epilogue that the matrix cores sit idle behind)
+__device__ __forceinline__ unsigned lo_pair(float x0, float x1, unsigned hpk) {
+    unsigned d;
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(d)
+        : "v"(x0), "v"(x1), "v"(hpk));
+    return d;
+}
 __device__ __forceinline__ int kmap(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }   // C/D row of register e, lane half h
 
 // LDS-DMA through inline asm: with the builtin, hipcc orders every later ds_read behind the pending LDS write with an
 // s_waitcnt vmcnt(0), i.e. it drains the prefetch the moment it is issued (measured in round 2, tools/micro/gemm_glds.hip).
 // The asm form is invisible to that analysis; the explicit vmcnt(0) + barrier at the top of a k-tile orders the reads.
-// ... with the address as a wave-uniform base + a 32-bit lane offset
-__device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned lds_dst) {
+// ... with the address as a wave-uniform base + a 32-bit lane offset, and the LDS destination as an SGPR base + a LITERAL: the
+// sum is formed into m0 inside the asm (a compiler-visible sum gets hoisted out of the k-loop as a loop invariant, runs out of
+// SGPRs, is spilled to VGPR lanes and comes back as a v_readlane — a VALU instruction in a load phase, see conv_pp_kernel)
+template <int LIT>
+__device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned lds_base) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %3, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(lds_dst)
-                 : "memory");
+                 : "v"(voff), "s"(sbase), "s"(lds_base), "n"(LIT)
+                 : "memory", "scc");
 }
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
@@ -95,8 +110,6 @@ struct PpParams {
     int M, N, K;
     int a_ncb, a_kb_steps;    // exponent blocks of the A operand along k, k-tiles per block
     int relu, group_rows, tiles_n;
-    int stagger;              // HP_PP_STAGGER (experiment): odd workgroups start this many s_sleep(127) (~3.9 us each) late
-    int dbg;                  // HP_PP_DBG (timing experiments only): 1 skip MFMAs, 2 skip DMA, 4 skip fragment reads, 8 skip barriers
 };
 
 template <int MODE, int TN>   // TN = 32-column tiles per wave: 2 (BN = 256) or 1 (BN = 128)
@@ -165,62 +178,103 @@ __global__ __launch_bounds__(512, 1) void conv_pp_kernel(const PpParams p) {
             oa[e] = (unsigned)(min(row0 + row, M - 1) - row0) * (unsigned)rowbytes + ((slot ^ ((row >> 1) & 7)) << 4);
         }
     };
-    auto issue = [&](int buf, int kt) {
-        const unsigned base = lds0 + (unsigned)(buf * kBufBytes) + (unsigned)(wid * 1024);
+    // The load phases run beside the partner wave's MFMA stream, which owns the VALU issue port (measured with in-kernel stamps:
+    // a v_readfirstlane or an address v_add in a load phase waits ~one MFMA, 18 of them = the whole burst).  So a load phase
+    // issues NO vector-ALU instruction: DMA destinations are SALU sums of one SGPR base, fragment addresses are sixteen VGPRs
+    // computed once (buffer x half x piece x operand; the per-tile offsets are ds_read immediates), kept opaque to the compiler
+    // (it would rematerialise them with VALU adds inside the loop), and the k-loop is unrolled by two so that the buffer index
+    // is a compile-time constant.
+    const unsigned s_ldsw = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(wid * 1024));
+    unsigned obe[2 * TN];                     // weight pieces: the 64-row step between a wave's instructions rides in the lane offset
+#pragma unroll
+    for (int e = 0; e < 2 * TN; ++e) {
+        obe[e] = ob + (unsigned)e * 64u * (unsigned)rowbytes;
+        asm volatile("" : "+v"(obe[e]));
+    }
+    // the 4 + 2 TN pieces of a k-tile in three parts (a k-tile's DMA is spread over three MFMA groups): part 0 = A pieces 0..2,
+    // part 1 = A piece 3 + weight pieces 0, 1, part 2 = weight pieces 2, 3 (TN = 2); part < 0: all of them
+    auto issue = [&](auto bufc, int kt, int part) {
+        constexpr int buf = decltype(bufc)::value;
         const unsigned char* asrc = Arow0 + kt * 128;
         const unsigned char* bsrc = Wrow0 + kt * 128;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) glds16s(asrc, oa[e], __builtin_amdgcn_readfirstlane(base + (unsigned)(e * 8192)));
-#pragma unroll
-        for (int e = 0; e < 2 * TN; ++e)
-            glds16s(bsrc + (long)e * 64 * rowbytes, ob, __builtin_amdgcn_readfirstlane(base + (unsigned)(kOpBytes + e * 8192)));
+        if (part < 0 || part == 0) {
+            glds16s<buf * kBufBytes + 0 * 8192>(asrc, oa[0], s_ldsw);
+            glds16s<buf * kBufBytes + 1 * 8192>(asrc, oa[1], s_ldsw);
+            glds16s<buf * kBufBytes + 2 * 8192>(asrc, oa[2], s_ldsw);
+        }
+        if (part < 0 || part == 1) {
+            glds16s<buf * kBufBytes + 3 * 8192>(asrc, oa[3], s_ldsw);
+            glds16s<buf * kBufBytes + kOpBytes + 0 * 8192>(bsrc, obe[0], s_ldsw);
+            glds16s<buf * kBufBytes + kOpBytes + 1 * 8192>(bsrc, obe[1], s_ldsw);
+        }
+        if (TN == 2 && (part < 0 || part == 2)) {
+            glds16s<buf * kBufBytes + kOpBytes + 2 * 8192>(bsrc, obe[2 * TN - 2], s_ldsw);
+            glds16s<buf * kBufBytes + kOpBytes + 3 * 8192>(bsrc, obe[2 * TN - 1], s_ldsw);
+        }
     };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
 
     // fragment addresses: row * 128 + ((chunk ^ swz) << 4); every row of this lane has swz = (r >> 1) & 7 (rows differ by
     // multiples of 32)
     const int swz = (r >> 1) & 7;
     const int fa0 = (wm * 128 + r) * 128, fb0 = kOpBytes + (wn * 32 * TN + r) * 128;
-    struct Frag {
-        f16x8 ah[4], al[4], bh[TN], bl[TN];
+    unsigned adA[2][2][2], adB[2][2][2];      // [buffer][half t][piece: hi, lo]
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int ch = ((2 * t + h) ^ swz) << 4, cl = ch ^ 64;     // hi chunk 2t+h, lo chunk 4+2t+h
+            adA[b2][t][0] = (unsigned)(b2 * kBufBytes + fa0 + ch);
+            adA[b2][t][1] = (unsigned)(b2 * kBufBytes + fa0 + cl);
+            adB[b2][t][0] = (unsigned)(b2 * kBufBytes + fb0 + ch);
+            adB[b2][t][1] = (unsigned)(b2 * kBufBytes + fb0 + cl);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                asm volatile("" : "+v"(adA[b2][t][q]));
+                asm volatile("" : "+v"(adB[b2][t][q]));
+            }
+        }
+    struct FragA {        // two 32-row tiles (i = 2 ip, 2 ip + 1) of one 16-deep half
+        f16x8 h[2], l[2];
     };
-    auto ldfrag = [&](Frag& f, int buf, int t) {
-        const unsigned char* base = lds + buf * kBufBytes;
-        const int ch = ((2 * t + h) ^ swz) << 4, cl = ch ^ 64;     // hi chunk 2t+h, lo chunk 4+2t+h
+    struct FragB {        // the wave's column tiles of one 16-deep half
+        f16x8 h[TN], l[TN];
+    };
+    auto ldA = [&](FragA& f, int buf, int t, int ip) {      // (buf, t, ip are compile-time constants at every call)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f.h[u] = *reinterpret_cast<const f16x8*>(lds + adA[buf][t][0] + (2 * ip + u) * 32 * 128);
+            f.l[u] = *reinterpret_cast<const f16x8*>(lds + adA[buf][t][1] + (2 * ip + u) * 32 * 128);
+        }
+    };
+    auto ldB = [&](FragB& f, int buf, int t) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            f.bh[j] = *reinterpret_cast<const f16x8*>(base + fb0 + j * 32 * 128 + ch);
-            f.bl[j] = *reinterpret_cast<const f16x8*>(base + fb0 + j * 32 * 128 + cl);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f.ah[i] = *reinterpret_cast<const f16x8*>(base + fa0 + i * 32 * 128 + ch);
-            f.al[i] = *reinterpret_cast<const f16x8*>(base + fa0 + i * 32 * 128 + cl);
+            f.h[j] = *reinterpret_cast<const f16x8*>(lds + adB[buf][t][0] + j * 32 * 128);
+            f.l[j] = *reinterpret_cast<const f16x8*>(lds + adB[buf][t][1] + j * 32 * 128);
         }
     };
     f32x16 acc[4][TN];
-    auto mma = [&](const Frag& f) {
+    // 6 TN MFMAs, product-major: consecutive MFMAs go to different accumulators; per accumulator the order is hi.hi, hi.lo, lo.hi
+    auto mma = [&](const FragA& a, const FragB& b, int ip) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if (MODE == 1) {   // rows = points
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
-                } else {           // rows = channels (the transposed tile: same products, same k order)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.ah[i], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[j], f.ah[i], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.al[i], acc[i][j], 0, 0, 0);
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const f16x8 xa = pr == 2 ? a.l[u] : a.h[u], xb = pr == 1 ? b.l[j] : b.h[j];
+                    f32x16& c = acc[2 * ip + u][j];
+                    if (MODE == 1) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, xb, c, 0, 0, 0);   // rows = points
+                    else c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xb, xa, c, 0, 0, 0);             // rows = channels
                 }
-            }
     };
 
     const int KT = K >> 5;
     const int* aexp_z = p.aexp + z * p.sWs;
-    if (p.stagger && (wg & 1))
-        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     set_tile(wg);
-    issue(0, 0);
+    issue(B0{}, 0, -1);
     for (int tile = wg; tile < ntiles; tile += nwg) {
         const int tile_m = tile / p.tiles_n, row0 = tile_m * 256;
         const int tile128 = tile_m * 2 + wm;            // this wave's row tile
@@ -235,37 +289,80 @@ __global__ __launch_bounds__(512, 1) void conv_pp_kernel(const PpParams p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-        // One barrier per k-tile: [my DMA pieces of tile kt have landed | barrier: everybody's have, and everybody is done with
-        // the other buffer | DMA tile kt+1 -> the other buffer | 24 fragment reads + 48 MFMAs on tile kt].  k-tile 0 of this
-        // tile was issued before the loop / before the previous tile's epilogue (whose stores are younger: vmcnt(0) waits for
-        // them too — they have had the whole epilogue to drain).
-        for (int kt = 0; kt < KT; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!(p.dbg & 8)) __builtin_amdgcn_s_barrier();
-            if (kt + 1 < KT && !(p.dbg & 2)) issue((kt + 1) & 1, kt + 1);
+        // STREAM schedule (all 8 waves alike, ONE barrier per k-tile).  A k-tile is four groups of 6 TN MFMAs (half t x row pair
+        // ip); while a group's MFMAs issue, the fragments of the NEXT group are on their way from LDS (two A sets, two B sets
+        // in registers) and two or three DMA instructions of a later k-tile are issued, so neither an LDS round trip nor a DMA
+        // issue sits in front of an MFMA:
+        //   G0  A1 <- (t0, ip1)                       | DMA(kt+1) part 1 | MFMA(A0, B0, ip0)
+        //   G1  A0 <- (t1, ip0), B1 <- (t1)           | DMA(kt+1) part 2 | MFMA(A1, B0, ip1)
+        //   G2  A1 <- (t1, ip1)                                          | MFMA(A0, B1, ip0)
+        //       wait: A1 here, my pieces of tile kt+1 landed | barrier (nobody reads this buffer any more; tile kt+1 complete)
+        //   G3  A0, B0 <- tile kt+1 (t0, ip0) from the OTHER buffer | DMA(kt+2) part 0 -> this buffer | MFMA(A1, B1, ip1)
+        // (Round 4 tried a two-group ping-pong — one wave of a SIMD in an MFMA phase while its partner loads — first: in-kernel
+        //  stamps showed the loading wave making no progress beside a back-to-back MFMA stream, even with s_setprio and with
+        //  load phases free of vector-ALU instructions: 93 us per conv5 either way.  DESIGN.md 7b.)
+        // k-tile 0 of this tile was issued before the previous tile's epilogue (whose stores are younger: vmcnt(0) waits for them
+        // too — they have had the whole epilogue to drain).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // tile 0 has landed, everybody's pieces
+        if (KT > 1) issue(B1{}, 1, -1);
+        FragA A0, A1;
+        FragB Bt0, Bt1;
+        ldA(A0, 0, 0, 0);
+        ldB(Bt0, 0, 0);
+        auto ktile = [&](int kt, auto bufc) {
+            constexpr int buf = decltype(bufc)::value;
+            using OB = std::integral_constant<int, buf ^ 1>;
             if (p.a_ncb > 1 && kt > 0 && kt % p.a_kb_steps == 0) {   // (wave-uniform) the A operand's exponent changes here
                 const int en = aexp[kt / p.a_kb_steps];
-                const float f = pow2f(en - ex);
+                const float sc = pow2f(en - ex);
                 ex = en;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) acc[i][j][e] *= f;
+                        for (int e = 0; e < 16; ++e) acc[i][j][e] *= sc;
             }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                Frag f;
-                if (!(p.dbg & 4)) ldfrag(f, kt & 1, t);
-                if (!(p.dbg & 1)) mma(f);
+            // ---- G0
+            ldA(A1, buf, 0, 1);
+            if (kt > 0 && kt + 1 < KT) issue(OB{}, kt + 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(A0, Bt0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- G1
+            ldA(A0, buf, 1, 0);
+            ldB(Bt1, buf, 1);
+            if (kt > 0 && kt + 1 < KT) issue(OB{}, kt + 1, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(A1, Bt0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- G2
+            ldA(A1, buf, 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(A0, Bt1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- G3
+            if (kt + 2 < KT) issue(bufc, kt + 2, 0);
+            if (kt + 1 < KT) {
+                ldA(A0, buf ^ 1, 0, 0);
+                ldB(Bt0, buf ^ 1, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            mma(A1, Bt1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        for (int kt = 0; kt < KT; kt += 2) {      // (KT is even: launch_pp)
+            ktile(kt, B0{});
+            ktile(kt + 1, B1{});
         }
-        if (tile + nwg < ntiles) {   // the next tile's first k-tile flies under this tile's epilogue
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();          // (KT even: the last k-tile sat in buffer 1; buffer 0 has been free for a k-tile)
+        // (the last k-tile's fragments were in registers before its barrier: both buffers are free)
+        if (tile + nwg < ntiles) {   // the next tile's first k-tile flies under this tile's epilogue (both buffers are free)
             set_tile(tile + nwg);
-            if (!(p.dbg & 2)) issue(0, 0);
+            issue(B0{}, 0, -1);
         }
         __builtin_amdgcn_sched_barrier(0);
 
@@ -309,7 +406,7 @@ __global__ __launch_bounds__(512, 1) void conv_pp_kernel(const PpParams p) {
         // ---- MODE 0: bias, ReLU, block maximum, split, 16-byte stores.  acc[i][j][e]: channel col0 + wn*32*TN + 32 j + kmap(e, h),
         //      point row0 + wm*128 + 32 i + r.  (Rows past M repeat row M-1 — the DMA clamps —, so they cannot raise the maximum.)
         float m = 0.f;
-        const float usA = pow2f(-ex);
+        const float usA = pow2f(-ex), floor_v = p.relu ? 0.f : -__builtin_inff();
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -321,8 +418,8 @@ __global__ __launch_bounds__(512, 1) void conv_pp_kernel(const PpParams p) {
                     const float us = us4[u] * usA;      // product of two powers of two: exact
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        float v = __builtin_fmaf(acc[i][j][e + u], us, bv4[u]);     // (= acc*us + bias: acc*us is exact)
-                        v = p.relu ? fmaxf(v, 0.f) : v;
+                        // (= acc*us + bias: acc*us is exact; ReLU as a max with 0 or -inf: no select per element)
+                        const float v = fmaxf(__builtin_fmaf(acc[i][j][e + u], us, bv4[u]), floor_v);
                         acc[i][j][e + u] = v;
                         m = fmaxf(m, fabsf(v));
                     }
@@ -349,10 +446,8 @@ __global__ __launch_bounds__(512, 1) void conv_pp_kernel(const PpParams p) {
 #pragma unroll
                     for (int pr = 0; pr < 2; ++pr) {
                         const float x0 = acc[i][j][4 * q + 2 * pr] * sx, x1 = acc[i][j][4 * q + 2 * pr + 1] * sx;
-                        const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
-                        H[q][pr] = pack2(h0, h1);
-                        // x - hi through an fma (one rounding either way): lets the backend use v_fma_mix on the f16 operand
-                        L[q][pr] = pack2((_Float16)__builtin_fmaf(x0, 1.0f, -(float)h0), (_Float16)__builtin_fmaf(x1, 1.0f, -(float)h1));
+                        H[q][pr] = pack2((_Float16)x0, (_Float16)x1);
+                        L[q][pr] = lo_pair(x0, x1, H[q][pr]);
                     }
                 // lanes < 32 hold channels 8q + 0..3, lanes >= 32 channels 8q + 4..7 of group q: a half exchange of the pair
                 // (q, q+1) leaves chunk q (8 channels, 16 bytes) in the lower lanes and chunk q+1 in the upper ones
@@ -368,9 +463,7 @@ __global__ __launch_bounds__(512, 1) void conv_pp_kernel(const PpParams p) {
                         L[q][pr] = s2[0];
                         L[q + 1][pr] = s2[1];
                     }
-                    if (p.dbg & 16) {
-                        asm volatile("" ::"v"(H[q][0]), "v"(H[q][1]), "v"(H[q + 1][0]), "v"(H[q + 1][1]), "v"(L[q][0]), "v"(L[q][1]), "v"(L[q + 1][0]), "v"(L[q + 1][1]));
-                    } else if (row < M) {
+                    if (row < M) {
                         *reinterpret_cast<u32x4*>(line + q * 16) = u32x4{H[q][0], H[q][1], H[q + 1][0], H[q + 1][1]};
                         *reinterpret_cast<u32x4*>(line + 64 + q * 16) = u32x4{L[q][0], L[q][1], L[q + 1][0], L[q + 1][1]};
                     }
@@ -532,12 +625,6 @@ int launch_pp(int mode, int n, const PpParams& p, hipStream_t stream) {
     if (p.N % bn || p.K % 64 || p.M <= 0) return -1;       // (K % 64: an even number of k-tiles — the two LDS buffers alternate)
     PpParams q = p;
     q.tiles_n = p.N / bn;
-    {
-        const char* e = getenv("HP_PP_DBG");
-        q.dbg = e ? atoi(e) : 0;
-        const char* g = getenv("HP_PP_STAGGER");
-        q.stagger = (g && mode == 0) ? atoi(g) : 0;
-    }
     // persistent workgroups: one per CU (256), fewer when there are fewer tiles; a multiple of 8 (XCD remap) and of tiles_n
     const long tiles = (long)((p.M + 255) / 256) * q.tiles_n;
     static const int kCus = [] {
