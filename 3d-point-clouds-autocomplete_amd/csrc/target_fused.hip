@@ -380,74 +380,6 @@ __global__ __launch_bounds__(512) void target_fwd_f16_kernel(int N, int iters, c
     }
 }
 
-// dX on the f16 pipe: out (TI tiles, Cin) = (W^T . delta (TO tiles, Cout)) * (hprev > 0), W (32*TO x 32*TI) as the forward's
-// f16 image.  The contraction now runs over W's ROWS, along which the forward's per-row weight scale varies: it is folded
-// into delta first (an exact power of two per register), then delta gets this wave's scale like any activation.  A lane's A
-// fragment is a column of the image — eight 2-byte reads per piece (hi, lo): its row set is fixed by the registers that hold
-// delta (k order of the accumulator tile), its column by the lane's channel.
-template <int TO, int TI>
-__device__ __forceinline__ void layer_dx_f16(const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
-                                             const float* __restrict__ wsc, const f32x16 (&delta)[TO], const f32x16 (&hprev)[TI],
-                                             f32x16 (&out)[TI], int r, int h) {
-    constexpr int CIN = 32 * TI;
-    float m = 0.f;
-#pragma unroll
-    for (int to = 0; to < TO; ++to)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) m = fmaxf(m, fabsf(delta[to][e] * wsc[to * 32 + kmap(e, h)]));
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    const int ex = 14 - f_frexp(m);
-    const float sx = f_pow2(ex), inv = f_pow2(-ex);
-    f16x8 bh[TO][2], bl[TO][2];
-#pragma unroll
-    for (int to = 0; to < TO; ++to)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int e = 8 * s + j;
-                const float xs = delta[to][e] * (wsc[to * 32 + kmap(e, h)] * sx);
-                const _Float16 hh = (_Float16)xs;
-                bh[to][s][j] = hh;
-                bl[to][s][j] = (_Float16)(xs - (float)hh);
-            }
-    // this lane's channel inside a 32-block of a row: granule (s', g', h') stored at (s', h', g')
-    const int perm = (r & 16) | ((r & 4) << 1) | ((r & 8) >> 1) | (r & 3);
-#pragma unroll
-    for (int ti = 0; ti < TI; ++ti) {
-        const int pos = 32 * ti + perm, chunkpos = pos >> 3, within = pos & 7;
-        // rows 32 to + 16 s + rl_j, rl_j = 8 (j>>2) + 4 h + (j&3): the swizzle looks at the row's low four bits only, so the
-        // eight column addresses are per-lane bases and (to, s) an immediate offset
-        int base[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int rl = 8 * (j >> 2) + 4 * h + (j & 3);
-            base[j] = rl * CIN + (swz_chunk<CIN>(rl, chunkpos) << 3) + within;
-        }
-        f32x16 acc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-        for (int to = 0; to < TO; ++to)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int o = (32 * to + 16 * s) * CIN;
-                f16x8 ah, al;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    ah[j] = Whi[base[j] + o];
-                    al[j] = Wlo[base[j] + o];
-                }
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[to][s], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[to][s], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[to][s], acc, 0, 0, 0);
-            }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) out[ti][e] = hprev[ti][e] > 0.f ? acc[e] * inv : 0.f;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
@@ -771,165 +703,6 @@ __global__ __launch_bounds__(256, 1) void target_bwd_kernel(int N, int iters, co
     }
 }
 
-// The same backward with the forward recomputation and the three dX contractions on the f16 pipe (layer_fwd_f16, layer_dx_f16:
-// the f16 image of theta replaces the fp32 one); the dW contractions over the points stay on the fp32 pipe from the fp32 stage.
-__global__ __launch_bounds__(256, 1) void target_bwd_f16_kernel(int N, int iters, const float* __restrict__ theta, int theta_ld,
-                                                            const float* __restrict__ pts, const float* __restrict__ gy,
-                                                            float* __restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) float lf[kFwdFloats + kStageFloats];
-    __shared__ __attribute__((aligned(16))) _Float16 lh[kFwdHalfs];
-    float* st = lf + kFwdFloats;
-    const int cloud = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    load_theta_f16<256>(theta + (long)cloud * theta_ld, lf, lh, tid);
-    const float* P = pts + (long)cloud * N * 3;
-    const float* G = gy + (long)cloud * N * 3;
-
-    // this wave's share of d theta (see the table in the file header)
-    f32x16 acc4[2], acc3[2], accs, acc1;   // dW4[:, wave-th cin tile], dW3[wave-th cout tile, :], small tile, dW1|db1
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        acc4[0][e] = acc4[1][e] = acc3[0][e] = acc3[1][e] = accs[e] = acc1[e] = 0.f;
-    }
-    float db4[2] = {0.f, 0.f}, db3 = 0.f, dbs = 0.f;   // row sums of this lane's A fragments
-    const int pl = (wave & 1) * 32 + r;                // this lane's point inside a 64-point stage half
-
-    for (int it = 0; it < iters; ++it) {
-        const int p0 = (blockIdx.x * iters + it) * 128;
-        if (p0 >= N) break;                            // uniform over the workgroup
-        const int pt = p0 + wave * 32 + r, pc = min(pt, N - 1);
-        const bool live = pt < N;
-        const float x = P[pc * 3], y = P[pc * 3 + 1], z = P[pc * 3 + 2];
-        float g[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) g[c] = live ? G[pc * 3 + c] : 0.f;
-        if (it == 0) __syncthreads();                  // theta image complete
-
-        // ---- recompute the forward
-        f32x16 h1[1], h2[2], h3[4], h4[2];
-        layer1_at(lf + FW1, lf + FB1, x, y, z, h, h1[0]);
-        layer_fwd_f16<1, 2>(lh + HW2, lh + HW2 + C2 * C1, lf + FS2, lf + FB2, h1, h2, r, h);
-        layer_fwd_f16<2, 4>(lh + HW3, lh + HW3 + C3 * C2, lf + FS3, lf + FB3, h2, h3, r, h);
-        layer_fwd_f16<4, 2>(lh + HW4, lh + HW4 + C4 * C3, lf + FS4, lf + FB4, h3, h4, r, h);
-
-        // ---- delta4 = (W5^T grad_y) * (h4 > 0)
-        f32x16 d4[2];
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int k = ti * 32 + kmap(e, h);
-                float t = g[0] * lf[FW5 + k];
-                t = __builtin_fmaf(g[1], lf[FW5 + C4 + k], t);
-                t = __builtin_fmaf(g[2], lf[FW5 + 2 * C4 + k], t);
-                d4[ti][e] = h4[ti][e] > 0.f ? t : 0.f;
-            }
-
-        // ---- group A: dW5 (+db5), dW4 (+db4)
-#pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
-            __syncthreads();
-            if ((wave >> 1) == half) {
-                if (h == 0) {
-                    st[(RA_GY + 0) * LDS_ST + pl] = g[0];
-                    st[(RA_GY + 1) * LDS_ST + pl] = g[1];
-                    st[(RA_GY + 2) * LDS_ST + pl] = g[2];
-                }
-                stage_put<2>(st, RA_H4, h4, pl, h);
-                stage_put<2>(st, RA_D4, d4, pl, h);
-                stage_put<4>(st, RA_H3, h3, pl, h);
-            }
-            __syncthreads();
-            dw_pair_a(st, RA_D4, RA_D4 + 32, RA_H3 + wave * 32, r, h, acc4[0], acc4[1], db4[0], db4[1]);   // db4: wave 0's copy is stored
-            if (wave >= 2) {
-                const float s5 = dw_tile<true, false>(st, RA_GY, RA_H4 + (wave - 2) * 32, r, h, accs, 3);
-                if (wave == 2) dbs += s5;
-            }
-        }
-
-        // ---- delta3, group B: dW3 (+db3)
-        f32x16 d3[4];
-        layer_dx_f16<2, 4>(lh + HW4, lh + HW4 + C4 * C3, lf + FS4, d4, h3, d3, r, h);
-#pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
-            __syncthreads();
-            if ((wave >> 1) == half) {
-                stage_put<4>(st, RB_D3, d3, pl, h);
-                stage_put<2>(st, RB_H2, h2, pl, h);
-            }
-            __syncthreads();
-            dw_pair_b(st, RB_D3 + wave * 32, RB_H2, RB_H2 + 32, r, h, acc3[0], acc3[1], db3);
-        }
-
-        // ---- delta2, delta1, group C: dW2 (+db2), dW1|db1
-        f32x16 d2[2], d1[1];
-        layer_dx_f16<4, 2>(lh + HW3, lh + HW3 + C3 * C2, lf + FS3, d3, h2, d2, r, h);
-        layer_dx_f16<2, 1>(lh + HW2, lh + HW2 + C2 * C1, lf + FS2, d2, h1, d1, r, h);
-#pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
-            __syncthreads();
-            if ((wave >> 1) == half) {
-                stage_put<2>(st, RC_D2, d2, pl, h);
-                stage_put<1>(st, RC_H1, h1, pl, h);
-                stage_put<1>(st, RC_D1, d1, pl, h);
-                if (h == 0) {
-                    st[(RC_H0 + 0) * LDS_ST + pl] = x;
-                    st[(RC_H0 + 1) * LDS_ST + pl] = y;
-                    st[(RC_H0 + 2) * LDS_ST + pl] = z;
-                }
-            }
-            __syncthreads();
-            if (wave < 2) dbs += dw_tile<false, false>(st, RC_D2 + wave * 32, RC_H1, r, h, accs);
-            if (wave == 3) (void)dw_tile<false, true>(st, RC_D1, RC_H0, r, h, acc1, 32, 3, true);
-        }
-    }
-
-    // ---- this workgroup's partial d theta, theta layout.  D tile: row = kmap(e,h), col = r.
-    float* out = partial + ((long)cloud * gridDim.x + blockIdx.x) * kTheta;
-#pragma unroll
-    for (int to = 0; to < 2; ++to)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) out[OW4 + (to * 32 + kmap(e, h)) * C3 + wave * 32 + r] = acc4[to][e];
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) out[OW3 + (wave * 32 + kmap(e, h)) * C2 + ti * 32 + r] = acc3[ti][e];
-    {
-        const float t = db3 + __shfl_xor(db3, 32, 64);
-        if (h == 0) out[OB3 + wave * 32 + r] = t;
-    }
-    if (wave < 2) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) out[OW2 + (wave * 32 + kmap(e, h)) * C1 + r] = accs[e];
-        const float t = dbs + __shfl_xor(dbs, 32, 64);
-        if (h == 0) out[OB2 + wave * 32 + r] = t;
-    } else {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int c = kmap(e, h);
-            if (c < 3) out[OW5 + c * C4 + (wave - 2) * 32 + r] = accs[e];
-        }
-        if (wave == 2) {
-            const float t = dbs + __shfl_xor(dbs, 32, 64);
-            if (h == 0 && r < 3) out[OB5 + r] = t;
-        }
-    }
-    if (wave == 0) {
-#pragma unroll
-        for (int to = 0; to < 2; ++to) {
-            const float t = db4[to] + __shfl_xor(db4[to], 32, 64);
-            if (h == 0) out[OB4 + to * 32 + r] = t;
-        }
-    }
-    if (wave == 3) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int c = kmap(e, h);
-            if (r < 3) out[OW1 + c * 3 + r] = acc1[e];
-            else if (r == 3) out[OB1 + c] = acc1[e];
-        }
-    }
-}
-
 // grad_theta[b][i] = sum_s partial[b][s][i], s ascending
 __global__ __launch_bounds__(256) void target_reduce_kernel(int S, const float* __restrict__ partial, float* __restrict__ gth,
                                                             int theta_ld) {
@@ -956,22 +729,9 @@ bool g_fwd_f16 = [] {
     return !(e && e[0] == '0');
 }();
 
-// Prototype, OFF by default (HP_TARGET_BWD_F16=1 / hp_target_fused_set_bwd_f16(1)): the backward with its forward recomputation
-// and its three dX contractions on the f16 pipe.  Parity-tested, but 147 us against the fp32 kernel's 151: at one wave per SIMD
-// the column gathers of the W^T fragments (576 two-byte LDS reads per 32 points) and the conversions cost what the MFMAs save
-// while the dW contractions over the points (28.7k of the remaining 35.6k MFMA cycles per iteration) are still fp32.  DESIGN 7b.
-bool g_bwd_f16 = [] {
-    const char* e = getenv("HP_TARGET_BWD_F16");
-    return e && e[0] == '1';
-}();
-
+// (Round 3's f16-pipe backward prototype — 147 us against this kernel's 151, 512 VGPRs and 240 B of scratch — lives as a patch in
+// tools/micro/target_bwd_f16.patch, not in the shipped library: DESIGN.md 7b.)
 }  // namespace
-
-HP_API int hp_target_fused_set_bwd_f16(int on) {
-    const int was = g_bwd_f16;
-    g_bwd_f16 = on != 0;
-    return was;
-}
 
 // The fused forward's hidden layers on the f16 matrix pipe with split fp32 operands (default) or on the fp32 one (0; also
 // environment HP_TARGET_F16=0).  Returns the previous setting.
@@ -1007,10 +767,7 @@ HP_API int hp_target_fused_backward(int B, int N, const float* theta, int theta_
     const int S = bwd_splits(B, N);
     const int blocks = (N + 127) / 128;
     const int iters = (blocks + S - 1) / S;
-    if (g_bwd_f16)
-        hipLaunchKernelGGL(target_bwd_f16_kernel, dim3(S, B), dim3(256), 0, stream, N, iters, theta, theta_ld, pts, grad_y, ws);
-    else
-        hipLaunchKernelGGL(target_bwd_kernel, dim3(S, B), dim3(256), 0, stream, N, iters, theta, theta_ld, pts, grad_y, ws);
+    hipLaunchKernelGGL(target_bwd_kernel, dim3(S, B), dim3(256), 0, stream, N, iters, theta, theta_ld, pts, grad_y, ws);
     hipLaunchKernelGGL(target_reduce_kernel, dim3((kTheta + 255) / 256, B), dim3(256), 0, stream, S, ws, grad_theta, theta_ld);
     HP_RETURN_LAST_ERROR();
 }

@@ -354,9 +354,6 @@ long hp_target_fused_workspace_floats(int B, int N);
  * forward (also: environment HP_TARGET_F16=0).  Returns the previous setting. */
 /* [test hook: process-wide, not thread-safe — see the header comment] */
 int hp_target_fused_set_f16(int on);
-/* Prototype switch, off by default: the fused backward with its forward recomputation and dX contractions on the f16 pipe
- * (parity-tested; not faster than the fp32 kernel yet — DESIGN.md 7b).  Returns the previous setting. */
-int hp_target_fused_set_bwd_f16(int on);
 int hp_target_fused_forward(int B, int N, const float* theta, int theta_ld, const float* pts, float* y, hpStream_t stream);
 int hp_target_fused_backward(int B, int N, const float* theta, int theta_ld, const float* pts, const float* grad_y,
                              float* grad_theta, float* ws, hpStream_t stream);

@@ -613,20 +613,12 @@ def test_target_network_forward_backward_vs_oracle(ref, fused, B, N):
         ops.FUSED_TARGET_NETWORK = True
 
 
-@pytest.mark.parametrize("bwd_f16", [0, 1])
-def test_target_fused_c_abi_padded_theta_rows_and_determinism(ref, bwd_f16):
+def test_target_fused_c_abi_padded_theta_rows_and_determinism(ref):
     """hp_target_fused_forward/backward straight through the C ABI with theta rows padded (theta_ld > 19011, what a
     caller slicing a wider buffer hands over): the padding is neither read into the result nor written, and the
-    backward (per-workgroup partials added in order) is bit-identical run to run.  bwd_f16 = 1: the prototype backward with
-    its forward recomputation and dX contractions on the f16 pipe (off by default), same bars."""
-    import ctypes
-    from hyperpocket_amd._lib import call, current_stream, load_library
-    lib = load_library()
-    prev_bwd = lib.hp_target_fused_set_bwd_f16(bwd_f16)
-    try:
-        _target_fused_c_abi(ref, lib)
-    finally:
-        lib.hp_target_fused_set_bwd_f16(prev_bwd)
+    backward (per-workgroup partials added in order) is bit-identical run to run."""
+    from hyperpocket_amd._lib import load_library
+    _target_fused_c_abi(ref, load_library())
 
 
 def _target_fused_c_abi(ref, lib):
