@@ -511,6 +511,43 @@ class GemmF16x2:
         return self.C
 
 
+class GemmPP:
+    """Test / bench hook over hp_gemm_pp_*: C = act(X W^T + b) with BOTH operands in the piece format (csrc/conv_pp.hip — the
+    kernel layers 2..5 of the encoders' conv stack run since round 4): X and W are packed once by the constructor (one exponent
+    per 128 rows x `xcb` channels of X, one per row of W), `run(mode)` is the matrix-core launch alone — mode 0: the layer form
+    (P-format C inside the workspace; `result()` brings it to fp32), mode 1: the fused max-pool's first stage (per-128-row-tile
+    column maxima of X W^T + b and their rows; `partials()`)."""
+
+    def __init__(self, X, W, bias, relu=False, xcb=None, group_rows=None):
+        for t, n in ((X, "X"), (W, "W"), (bias, "bias")):
+            check_input(t, n)
+        self.M, self.K = X.shape
+        self.N = W.shape[0]
+        self.xcb = int(xcb or min(self.K, 256))
+        self.bias, self.relu = bias, int(relu)
+        self.group_rows = int(group_rows or 128 * ((self.M + 127) // 128))
+        self.ws = torch.empty((_long_fn("hp_gemm_pp_workspace_floats", c_long(self.M), self.N, self.K),), dtype=torch.float32,
+                              device=X.device)
+        self.dev = X.device
+        call("hp_gemm_pp_prepare", c_long(self.M), self.N, self.K, self.xcb, X, W, self.ws, current_stream(self.dev))
+
+    def run(self, mode=0):
+        call("hp_gemm_pp_run", c_long(self.M), self.N, self.K, self.xcb, self.bias, self.relu, int(mode), self.group_rows, self.ws,
+             current_stream(self.dev))
+
+    def result(self):
+        C = torch.empty((self.M, self.N), dtype=torch.float32, device=self.dev)
+        call("hp_gemm_pp_unpack", c_long(self.M), self.N, self.K, self.ws, C, current_stream(self.dev))
+        return C
+
+    def partials(self):
+        tiles = (self.M + 127) // 128
+        cmax = torch.empty((tiles, self.N), dtype=torch.float32, device=self.dev)
+        cidx = torch.empty((tiles, self.N), dtype=torch.int32, device=self.dev)
+        call("hp_gemm_pp_partials", c_long(self.M), self.N, self.K, self.ws, cmax, cidx, current_stream(self.dev))
+        return cmax, cidx
+
+
 def gemm(A, B, bias=None, relu=False, trans_a=False, trans_b=True, mask=None, add=None, ksplit=1, rowsum=False, out=None,
          dyn_rows=None, dyn_k=None):
     """Thin test hook over hp_gemm_f32 for 2-D / 3-D (batched) fp32 tensors:

@@ -15,7 +15,7 @@ B=64 clouds per GPU, existing/missing (B,1024,3), gt (B,2048,3), fp32 ("Chamfer+
 value = clouds/s over all ranks (weak scaling: B per GPU fixed).
 
 One JSON line on rank 0; besides the contract keys it carries
-  roofline      the widest matrix kernel (conv5 of the encoder stack on the f16 pipe, split fp32 operands), timed live with HIP events
+  roofline      the widest matrix kernel (conv5 + max-pool of the encoder stack: f16 pipe, both operands stored as f16 piece pairs), timed live with HIP events
   roofline_emd  the EMD sweep family (45 % of the step): VALU issue cycles of the compiled loops / measured time
   cpu_baseline  the oracle's torch-CPU restatement of the reference step timed on this box's cores
   breakdown     extra figures (Chamfer-only step, per-op times) — informational
@@ -97,16 +97,17 @@ def event_time_ms(fn, iters, warm=2):
 
 
 def roofline_dominant_kernel(batch, n_half):
-    """The widest matrix kernel of the step: layer 5 of the encoders' conv stack, C(M x 512) = A(M x 512) W(512 x 512)^T + b with
-    M = B*1024 points (one encoder per launch here; the step batches both encoders into one launch of twice the tiles).
-    Round 3 moved it from the fp32 matrix pipe (gemm_kernel<128,128,4,2,16,4>, v_mfma_f32_32x32x2_f32, 0.79 of 157.3 TFLOP/s)
-    to csrc/conv_split.hip: each fp32 operand split into two f16 pieces, three f16 MFMA products per fp32-equivalent
-    product, fp32 accumulation, fp32-chain accuracy (tests/test_model_gpu.py).  Algorithmic flops = 2*M*512*512 (SURVEY §8d);
-    `achieved` is algorithmic TFLOP/s.  The roofline that bounds this kernel is the f16 matrix peak divided by the three
-    products it executes per algorithmic one — `peak`; `frac` = achieved / peak = executed f16 flops / f16 peak.
-    `vs_f32_mfma_peak` prices the same number against the fp32 matrix peak the previous kernel was bound by, and
-    `f32_mfma_kernel` is that previous kernel timed here on the same operands.
-    `traffic` (HBM bytes per launch) comes from the PMC passes recorded under profiles/ (FETCH_SIZE x2 correction +
+    """The widest matrix kernel of the step: layer 5 of the encoders' conv stack with its fused max-pool,
+    max over points of A(M x 512) W(512 x 512)^T + b, M = B*1024 points of one encoder (the step batches both encoders into one
+    launch of twice the tiles: `paired_launch` times that shape too).  Round 3 moved the layer from the fp32 matrix pipe
+    (gemm_kernel<128,128,4,2,16,4>, v_mfma_f32_32x32x2_f32, 0.79 of 157.3 TFLOP/s) to the f16 pipe with every fp32 operand as two
+    f16 pieces — three f16 MFMA products per fp32-equivalent product, fp32 accumulation (csrc/conv_split.hip, 0.30 of f16 / 3);
+    round 4 stores the activations already split (csrc/conv_pp.hip), so BOTH operands are DMA-staged into 256 x 256 tiles of a
+    persistent 8-wave workgroup per CU.  Algorithmic flops = 2*M*512*512; `achieved` is algorithmic TFLOP/s.  The
+    roofline that bounds the kernel is the f16 matrix peak divided by the three products it executes per algorithmic one —
+    `peak`; `frac` = achieved / peak = executed f16 flops / f16 peak.  `vs_f32_mfma_peak` prices the same number against the fp32
+    matrix peak rounds 1-2 were bound by; `round3_kernel` and `f32_mfma_kernel` are the previous kernels timed here on the same
+    operands.  `traffic` (HBM bytes per launch) comes from the PMC passes recorded under profiles/ (FETCH_SIZE x2 correction +
     WRITE_SIZE), measured at B=64."""
     from hyperpocket_amd import ops
     m = batch * n_half
@@ -116,8 +117,14 @@ def roofline_dominant_kernel(batch, n_half):
     c = torch.empty(m, 512, device="cuda")
     # 200 warm-up launches: the chip needs >20 ms of continuous load to reach the clock it then sustains — the state every
     # kernel of a training run executes in (tools/roof_sweep.py)
+    pp = ops.GemmPP(a, w, b, relu=False, xcb=256, group_rows=n_half)
+    ms = event_time_ms(lambda: pp.run(1), iters=100, warm=200)
+    a2 = torch.cat([a, a.flip(0)])
+    pp2 = ops.GemmPP(a2, w, b, relu=False, xcb=256, group_rows=n_half)
+    ms_pair = event_time_ms(lambda: pp2.run(1), iters=60, warm=100)
+    del pp2, a2
     g = ops.GemmF16x2(a, w, b, relu=False, out=c)
-    ms = event_time_ms(g.run, iters=100, warm=200)
+    ms_r3 = event_time_ms(g.run, iters=60, warm=100)
     ms32 = event_time_ms(lambda: ops.gemm(a, w, bias=b, out=c), iters=50, warm=100)
     flops = 2.0 * m * 512 * 512
     achieved = flops / (ms * 1e-3) / 1e12
@@ -126,15 +133,22 @@ def roofline_dominant_kernel(batch, n_half):
     pmc_name, pmc = latest_profile("pmc_gemm_conv5.json")
     if pmc and batch == 64 and n_half == 1024:
         rec = json.load(open(pmc))
-        if "conv_split" in rec.get("kernel", ""):
+        if "conv_pp" in rec.get("kernel", ""):
             traffic = rec["hbm_bytes_per_launch"]
-    return {"bound": "mfma", "kernel": "conv_split_kernel<false> (encoder conv5: M=B*1024, N=K=512; fp32 operands as 2 f16 pieces, "
-                                       "3 x v_mfma_f32_32x32x16_f16 per 32x32x16 block of products, fp32 accumulate)",
+    return {"bound": "mfma", "kernel": "conv_pp_kernel<1, 2> (encoder conv5 + fused max-pool: M=B*1024, N=K=512; both operands stored as "
+                                       "2 f16 pieces and DMA-staged, 3 x v_mfma_f32_32x32x16_f16 per 32x32x16 block of products, fp32 "
+                                       "accumulate)",
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4),
             "peak_is": f"f16 dense MFMA peak {PEAK_F16_MFMA_TFLOPS} TFLOP/s / 3 products per fp32-equivalent product",
             "executed_f16_tflops": round(3 * achieved, 1),
+            "paired_launch": {"what": "the step's launch: both encoders = twice the tiles (4 per persistent workgroup instead of 2)",
+                              "avg_launch_ms": round(ms_pair, 4), "achieved": round(2 * flops / (ms_pair * 1e-3) / 1e12, 2),
+                              "frac": round(2 * flops / (ms_pair * 1e-3) / 1e12 / peak, 4)},
             "vs_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 3),
+            "round3_kernel": {"kernel": "conv_split_kernel<false> (fp32 activations split in the consumer, 128x128 tiles; stores C)",
+                              "avg_launch_ms": round(ms_r3, 4), "achieved": round(flops / (ms_r3 * 1e-3) / 1e12, 2),
+                              "frac": round(flops / (ms_r3 * 1e-3) / 1e12 / peak, 4)},
             "f32_mfma_kernel": {"kernel": "gemm_kernel<128,128,4,2,16,4> (v_mfma_f32_32x32x2_f32)", "avg_launch_ms": round(ms32, 4),
                                 "achieved": round(flops / (ms32 * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                                 "frac": round(flops / (ms32 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
@@ -142,7 +156,7 @@ def roofline_dominant_kernel(batch, n_half):
             "traffic_source": f"profiles/{pmc_name} (rocprofv3 --pmc passes of this launch; not measured in this run)"
             if traffic is not None else None,
             "avg_launch_ms": round(ms, 4), "flops_per_launch": flops,
-            "algorithmic_bytes_per_launch": (2 * m * 512 + 512 * 512 + 512) * 4}
+            "algorithmic_bytes_per_launch": (m * 512 + 512 * 512 + 512 + 2 * (m // 128) * 512) * 4}
 
 
 def cpu_baseline(n_half, emd_coef, sample_b=4, timed_steps=2, full_b=64):
@@ -590,9 +604,12 @@ def main():
                                                            if args.batch == 32 else f"the metric's shape at B={args.batch}"),
                        "global_batch": args.batch * world, "points": args.points, "parallelism": f"dp{world}",
                        "params": 43328515,
-                       "arithmetic": "fp32 operands, fp32 accumulation, fp32 outputs throughout; the encoders' conv GEMMs form their "
-                                     "products on the f16 matrix pipe from two f16 pieces per fp32 operand (three products, error vs "
-                                     "fp64 = the fp32 fma chain's: tests/test_model_gpu.py; HP_CONV_SPLIT=0 restores fp32 MFMA)"},
+                       "arithmetic": "fp32 weights, fp32 accumulation, fp32 results throughout; the encoders' conv GEMMs form their "
+                                     "products on the f16 matrix pipe from two f16 pieces per fp32 operand (three products), and since "
+                                     "round 4 the hidden activations h1..h4 are STORED as such piece pairs with block exponents (22-23 "
+                                     "significant bits, same bytes as fp32; error vs fp64 within 2.5x rms / 3x max of the fp32 fma chain's, "
+                                     "pooled features within 2e-6: tests/test_model_gpu.py; HP_CONV_PRESPLIT=0 restores fp32 "
+                                     "activations, HP_CONV_SPLIT=0 the fp32 MFMA GEMMs)"},
             "final_loss": loss,
         }
         if not args.no_extras:
