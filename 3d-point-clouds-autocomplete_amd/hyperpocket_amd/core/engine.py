@@ -453,7 +453,8 @@ class TrainEngine:
     def synchronize(self):
         """finish_pending + wait for the device: after it the parameters are the state after `steps` whole steps."""
         self.finish_pending()
-        torch.cuda.current_stream(self.flat.flat.device).synchronize()
+        if self.flat.flat.is_cuda:       # (CPU tensors: the gloo host-logic tests; the collectives' waits above are blocking there)
+            torch.cuda.current_stream(self.flat.flat.device).synchronize()
 
     # ------------------------------------------------------------------ optimiser checkpoints (SURVEY §8f N1)
     def _moment_views(self, buf):
