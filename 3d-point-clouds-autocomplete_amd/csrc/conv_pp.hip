@@ -48,7 +48,6 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kTarget = 14;
 constexpr int kExpMax = HP_PP_EXP_MAX;
-constexpr int kOpBytes = 256 * 128;       // the A part of an LDS buffer: 256 rows x one 128-byte line
 
 __device__ __forceinline__ int frexp_exp(unsigned bits) {
     const int E = (int)((bits >> 23) & 0xff);
@@ -112,9 +111,15 @@ struct PpParams {
     int relu, group_rows, tiles_n;
 };
 
-template <int MODE, int TN>   // TN = 32-column tiles per wave: 2 (BN = 256) or 1 (BN = 128)
-__global__ __launch_bounds__(512, 1) void conv_pp_kernel(const PpParams p) {
-    constexpr int BN = 128 * TN;
+// TN = 32-column tiles per wave: 2 (BN = 256) or 1 (BN = 128); WM = 128-row wave rows per workgroup: 2 (256 rows, 8 waves, one
+// workgroup per CU) or 1 (128 rows, 4 waves, 64 KB of LDS at TN = 1: TWO workgroups per CU, so that one's epilogue — vector ALU
+// and stores, the matrix cores idle — runs beside the other's k-loop: the store layers)
+template <int MODE, int TN, int WM>
+__global__ __launch_bounds__(256 * WM, 2 / WM) void conv_pp_kernel(const PpParams p) {
+    constexpr int BN = 128 * TN, BM = 128 * WM, NW = 4 * WM;
+    constexpr int kOpBytes = BM * 128;       // the A part of an LDS buffer: BM rows x one 128-byte line
+    constexpr int NB = (BN / 8) / NW;          // weight-tile DMA instructions per wave
+    static_assert(NB == 2 || NB == 4, "tile shapes: 256x256/8 waves, 256x128/8 waves, 128x128/4 waves");
     constexpr int kBufBytes = kOpBytes + BN * 128;
     // [two operand buffers | per-channel epilogue table of this workgroup's BN columns: 2^-e_w, bias | 8 floats of exchange]
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * kBufBytes + BN * 8 + 64];
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(512, 1) void conv_pp_kernel(const PpParams p) {
         wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (wg >> 3);
     }
     const int z = blockIdx.y;
-    const int ntiles = ((p.M + 255) >> 8) * p.tiles_n;
+    const int ntiles = ((p.M + BM - 1) / BM) * p.tiles_n;
     const int tile_n = wg % p.tiles_n, col0 = tile_n * BN;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 2, wn = wid & 3, r = lane & 31, h = lane >> 5;
     const int K = p.K, M = p.M;
@@ -164,17 +169,17 @@ __global__ __launch_bounds__(512, 1) void conv_pp_kernel(const PpParams p) {
     const int sub = lane >> 3, slot = lane & 7;
     unsigned oa[4], ob;
     {
-        const int row = wid * 8 + sub;        // instruction e of the weight tile: + 64 e rows (uniform)
+        const int row = wid * 8 + sub;        // instruction e of the weight tile: + 8 NW e rows (uniform)
         ob = (unsigned)row * (unsigned)rowbytes + ((slot ^ ((row >> 1) & 7)) << 4);
     }
     const unsigned lds0 = (unsigned)(uintptr_t)lds;
     const unsigned char* Arow0 = Ab;
     auto set_tile = [&](int tile) {           // DMA source of the activation rows of `tile`
-        const int row0 = (tile / p.tiles_n) * 256;
+        const int row0 = (tile / p.tiles_n) * BM;
         Arow0 = Ab + (long)row0 * rowbytes;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int row = (e * 8 + wid) * 8 + sub;
+            const int row = (e * NW + wid) * 8 + sub;
             oa[e] = (unsigned)(min(row0 + row, M - 1) - row0) * (unsigned)rowbytes + ((slot ^ ((row >> 1) & 7)) << 4);
         }
     };
@@ -185,31 +190,35 @@ __global__ __launch_bounds__(512, 1) void conv_pp_kernel(const PpParams p) {
     // (it would rematerialise them with VALU adds inside the loop), and the k-loop is unrolled by two so that the buffer index
     // is a compile-time constant.
     const unsigned s_ldsw = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(wid * 1024));
-    unsigned obe[2 * TN];                     // weight pieces: the 64-row step between a wave's instructions rides in the lane offset
+    unsigned obe[NB];                     // weight pieces: the 64-row step between a wave's instructions rides in the lane offset
 #pragma unroll
-    for (int e = 0; e < 2 * TN; ++e) {
-        obe[e] = ob + (unsigned)e * 64u * (unsigned)rowbytes;
+    for (int e = 0; e < NB; ++e) {
+        obe[e] = ob + (unsigned)e * (8u * NW) * (unsigned)rowbytes;
         asm volatile("" : "+v"(obe[e]));
     }
-    // the 4 + 2 TN pieces of a k-tile in three parts (a k-tile's DMA is spread over three MFMA groups): part 0 = A pieces 0..2,
-    // part 1 = A piece 3 + weight pieces 0, 1, part 2 = weight pieces 2, 3 (TN = 2); part < 0: all of them
+    // the 4 + NB pieces of a k-tile in three parts (a k-tile's DMA is spread over three MFMA groups): part 0 = A pieces 0..2,
+    // part 1 = A piece 3 + weight pieces 0, 1, part 2 = weight pieces 2, 3 (when there are four); part < 0: all of them
     auto issue = [&](auto bufc, int kt, int part) {
         constexpr int buf = decltype(bufc)::value;
+        constexpr int PS = NW * 1024;                    // LDS distance between a wave's consecutive pieces
         const unsigned char* asrc = Arow0 + kt * 128;
         const unsigned char* bsrc = Wrow0 + kt * 128;
         if (part < 0 || part == 0) {
-            glds16s<buf * kBufBytes + 0 * 8192>(asrc, oa[0], s_ldsw);
-            glds16s<buf * kBufBytes + 1 * 8192>(asrc, oa[1], s_ldsw);
-            glds16s<buf * kBufBytes + 2 * 8192>(asrc, oa[2], s_ldsw);
+            glds16s<buf * kBufBytes + 0 * PS>(asrc, oa[0], s_ldsw);
+            glds16s<buf * kBufBytes + 1 * PS>(asrc, oa[1], s_ldsw);
+            glds16s<buf * kBufBytes + 2 * PS>(asrc, oa[2], s_ldsw);
         }
         if (part < 0 || part == 1) {
-            glds16s<buf * kBufBytes + 3 * 8192>(asrc, oa[3], s_ldsw);
-            glds16s<buf * kBufBytes + kOpBytes + 0 * 8192>(bsrc, obe[0], s_ldsw);
-            glds16s<buf * kBufBytes + kOpBytes + 1 * 8192>(bsrc, obe[1], s_ldsw);
+            glds16s<buf * kBufBytes + 3 * PS>(asrc, oa[3], s_ldsw);
+            glds16s<buf * kBufBytes + kOpBytes + 0 * PS>(bsrc, obe[0], s_ldsw);
+            glds16s<buf * kBufBytes + kOpBytes + 1 * PS>(bsrc, obe[1], s_ldsw);
         }
-        if (TN == 2 && (part < 0 || part == 2)) {
-            glds16s<buf * kBufBytes + kOpBytes + 2 * 8192>(bsrc, obe[2 * TN - 2], s_ldsw);
-            glds16s<buf * kBufBytes + kOpBytes + 3 * 8192>(bsrc, obe[2 * TN - 1], s_ldsw);
+        if (NB > 2 && (part < 0 || part == 2)) {
+#pragma unroll
+            for (int e = 2; e < NB; ++e) {
+                if (e == 2) glds16s<buf * kBufBytes + kOpBytes + 2 * PS>(bsrc, obe[NB > 2 ? 2 : 0], s_ldsw);
+                if (e == 3) glds16s<buf * kBufBytes + kOpBytes + 3 * PS>(bsrc, obe[NB > 3 ? 3 : 0], s_ldsw);
+            }
         }
     };
     using B0 = std::integral_constant<int, 0>;
@@ -276,8 +285,8 @@ __global__ __launch_bounds__(512, 1) void conv_pp_kernel(const PpParams p) {
     set_tile(wg);
     issue(B0{}, 0, -1);
     for (int tile = wg; tile < ntiles; tile += nwg) {
-        const int tile_m = tile / p.tiles_n, row0 = tile_m * 256;
-        const int tile128 = tile_m * 2 + wm;            // this wave's row tile
+        const int tile_m = tile / p.tiles_n, row0 = tile_m * BM;
+        const int tile128 = tile_m * WM + wm;            // this wave's row tile
         // exponents of this wave's 128 A rows, per block along k: wave-uniform -> scalar loads (no vector-memory traffic of the
         // compiler's beside the DMAs)
         const int* aexp = aexp_z + (long)__builtin_amdgcn_readfirstlane(min(tile128, (M - 1) >> 7) * p.a_ncb);
@@ -620,28 +629,46 @@ bool g_presplit = [] {
     return !(e && e[0] == '0');
 }();
 
+// column tile of a launch: 256 where the layer has that many columns — except the STORE layers when HP_PP_BN128=1 (experiment: every
+// store layer in 128-column tiles = the two-workgroups-per-CU shape)
+int pp_bn(int N, int mode) {
+    static const int kBn128 = [] {
+        const char* e = getenv("HP_PP_BN128");
+        return e ? atoi(e) : 0;
+    }();
+    return (N >= 256 && !(mode == 0 && kBn128)) ? 256 : 128;
+}
 int launch_pp(int mode, int n, const PpParams& p, hipStream_t stream) {
-    const int bn = p.N >= 256 ? 256 : 128;
+    const int bn = pp_bn(p.N, mode);
     if (p.N % bn || p.K % 64 || p.M <= 0) return -1;       // (K % 64: an even number of k-tiles — the two LDS buffers alternate)
     PpParams q = p;
     q.tiles_n = p.N / bn;
-    // persistent workgroups: one per CU (256), fewer when there are fewer tiles; a multiple of 8 (XCD remap) and of tiles_n
-    const long tiles = (long)((p.M + 255) / 256) * q.tiles_n;
+    // persistent workgroups: one per CU (256) — two of the 4-wave ones —, fewer when there are fewer tiles; a multiple of 8
+    // (XCD remap) and of tiles_n
+    static const int kSmall = [] {
+        const char* e = getenv("HP_PP_SMALL");      // 1 (default): store layers with 128-column tiles run as 128 x 128 / 4-wave workgroups
+        return e ? atoi(e) : 1;
+    }();
+    const bool small = mode == 0 && bn == 128 && kSmall;
+    const int bm = small ? 128 : 256;
+    const long tiles = (long)((p.M + bm - 1) / bm) * q.tiles_n;
     static const int kCus = [] {
         const char* e = getenv("HP_PP_WGS");
         return e ? atoi(e) : 256;
     }();
-    long wgs = std::min<long>(tiles, kCus / n > 0 ? kCus / n : 1);
+    const int per_cu = small ? 2 : 1;
+    long wgs = std::min<long>(tiles, kCus * per_cu / n > 0 ? kCus * per_cu / n : 1);
     const int mult = 8 * q.tiles_n / (q.tiles_n % 8 == 0 ? 8 : (8 % q.tiles_n == 0 ? q.tiles_n : 1));   // lcm(8, tiles_n) for tiles_n in {1,2,4,8}
     if (wgs >= mult) wgs = wgs / mult * mult;
     else wgs = (tiles >= q.tiles_n) ? q.tiles_n : wgs;
     const dim3 grid((unsigned)wgs, n);
     if (mode == 1) {
-        if (bn == 256) hipLaunchKernelGGL((conv_pp_kernel<1, 2>), grid, dim3(512), 0, stream, q);
-        else hipLaunchKernelGGL((conv_pp_kernel<1, 1>), grid, dim3(512), 0, stream, q);
+        if (bn == 256) hipLaunchKernelGGL((conv_pp_kernel<1, 2, 2>), grid, dim3(512), 0, stream, q);
+        else hipLaunchKernelGGL((conv_pp_kernel<1, 1, 2>), grid, dim3(512), 0, stream, q);
     } else {
-        if (bn == 256) hipLaunchKernelGGL((conv_pp_kernel<0, 2>), grid, dim3(512), 0, stream, q);
-        else hipLaunchKernelGGL((conv_pp_kernel<0, 1>), grid, dim3(512), 0, stream, q);
+        if (bn == 256) hipLaunchKernelGGL((conv_pp_kernel<0, 2, 2>), grid, dim3(512), 0, stream, q);
+        else if (small) hipLaunchKernelGGL((conv_pp_kernel<0, 1, 1>), grid, dim3(256), 0, stream, q);
+        else hipLaunchKernelGGL((conv_pp_kernel<0, 1, 2>), grid, dim3(512), 0, stream, q);
     }
     HP_RETURN_LAST_ERROR();
 }
@@ -649,6 +676,10 @@ int launch_pp(int mode, int n, const PpParams& p, hipStream_t stream) {
 }  // namespace
 
 bool hp_conv_presplit_enabled() { return g_presplit; }
+int hp_conv_pp_ncb(int l) {
+    static const int kC[5] = {0, 64, 128, 256, 512};
+    return l <= 1 ? 1 : kC[l] / pp_bn(kC[l], 0);
+}
 HP_API int hp_conv_presplit_set(int on) {
     const int was = g_presplit;
     g_presplit = on != 0;
@@ -658,7 +689,7 @@ HP_API int hp_conv_presplit_set(int on) {
 // exponent tables of the P-format activations h1..h4 inside the split area: 1, 1, 1, 2 column blocks per 128-row tile
 static inline long pexp_off(int l, long tp) { return hp_conv_pp_exp_offset(l, tp); }
 
-long hp_conv_pp_fmt_offset(long R) { return hp_conv_pp_exp_offset(4, hp_conv_split_tiles_pad(R)) + 2 * hp_conv_split_tiles_pad(R); }
+long hp_conv_pp_fmt_offset(long R) { return hp_conv_pp_exp_offset(5, hp_conv_split_tiles_pad(R)); }
 
 int hp_conv_pp_layer1(int n, const float* x, long sXz, const float* W, long sWz, const float* b, long sBz, float* h1, float* area0,
                       long sWs, long R, hipStream_t stream) {
@@ -680,8 +711,8 @@ int hp_conv_pp_layer(int l, int n, const float* X, const float* bias, long sBias
     PpParams p{};
     p.A = reinterpret_cast<const _Float16*>(X);
     p.aexp = reinterpret_cast<const int*>(area0 + pexp_off(l - 1, tp));
-    p.a_ncb = l == 5 ? 2 : 1;
     p.K = kKL[l - 2];
+    p.a_ncb = hp_conv_pp_ncb(l - 1);
     p.a_kb_steps = p.K / 32 / p.a_ncb;
     p.Whl = reinterpret_cast<const _Float16*>(area0 + HP_CS_HI_OFF) + 2 * kWOffL[l - 2];
     p.wexp = reinterpret_cast<const int*>(area0 + HP_CS_WEXP_OFF) + kRowsL[l - 2];
@@ -715,7 +746,7 @@ int hp_conv_pp_unpack_ws(float* ws, long R, hipStream_t stream) {
         const long lines = R * (C / 32);
         const unsigned blocks = (unsigned)std::min<long>((lines + 255) / 256, 8192);
         hipLaunchKernelGGL(pp_unpack_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const _Float16*>(hl),
-                           reinterpret_cast<const int*>(area + pexp_off(l, tp)), R, C, l == 4 ? 256 : C, hl, fmt);
+                           reinterpret_cast<const int*>(area + pexp_off(l, tp)), R, C, C / hp_conv_pp_ncb(l), hl, fmt);
         hl += R * C;
     }
     hipLaunchKernelGGL(pp_set_fmt_kernel, dim3(1), dim3(1), 0, stream, fmt, HP_PP_FMT_F32);
@@ -789,7 +820,7 @@ HP_API int hp_gemm_pp_unpack(long M, int N, int K, const float* ws, float* C, hi
     const PpWs w = pp_ws(const_cast<float*>(ws), M, N, K);
     const long lines = M * (N / 32);
     hipLaunchKernelGGL(pp_unpack_kernel, dim3((unsigned)std::min<long>((lines + 255) / 256, 8192)), dim3(256), 0, stream,
-                       reinterpret_cast<const _Float16*>(w.cp), reinterpret_cast<const int*>(w.cexp), M, N, N >= 256 ? 256 : 128, C,
+                       reinterpret_cast<const _Float16*>(w.cp), reinterpret_cast<const int*>(w.cexp), M, N, pp_bn(N, 0), C,
                        (const int*)nullptr);
     HP_RETURN_LAST_ERROR();
 }

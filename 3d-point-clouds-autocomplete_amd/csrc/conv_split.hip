@@ -437,7 +437,7 @@ bool g_enabled = [] {
 
 }  // namespace
 
-long hp_conv_split_area_floats(long R) { return HP_CS_AMAX_OFF + 9 * hp_conv_split_tiles_pad(R) + 4; }   // amax x 4, P-format exponents x 5, format word
+long hp_conv_split_area_floats(long R) { return HP_CS_AMAX_OFF + 20 * hp_conv_split_tiles_pad(R) + 4; }   // amax x 4, P-format exponents 4 x 4, format word
 bool hp_conv_split_enabled() { return g_enabled; }
 HP_API int hp_conv_split_set(int on) {
     const int was = g_enabled;

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(512) void enc_bwd_prep_kernel(const HpEncBwdArgs a)
 __global__ __launch_bounds__(256) void enc_bwd_gather_kernel(const HpEncBwdArgs a) {
     __shared__ int sarg[256];
     __shared__ float sdg[256];
-    __shared__ float sus[256][2];
+    __shared__ float sus[256][4];
     __shared__ float4 red[3][64][2];
     const int id = blockIdx.x;
     const int z = a.n == 2 ? (id & 1) : 0, rest = a.n == 2 ? (id >> 1) : id;
@@ -200,8 +200,8 @@ __global__ __launch_bounds__(256) void enc_bwd_gather_kernel(const HpEncBwdArgs 
                 sdg[tid] = s.dg[row];
                 if (pfmt) {
                     const long hrow = (long)(c0 + tid) * a.Np + arg;
-                    sus[tid][0] = pexp_unscale(s.pexp[4][(hrow >> 7) * 2]);
-                    sus[tid][1] = pexp_unscale(s.pexp[4][(hrow >> 7) * 2 + 1]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sus[tid][k] = pexp_unscale(s.pexp[4][(hrow >> 7) * s.pncb[4] + min(k, s.pncb[4] - 1)]);
                 }
             }
             __syncthreads();
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void enc_bwd_gather_kernel(const HpEncBwdArgs 
 #pragma unroll 4
             for (int b = g; b < nb; b += 4) {
                 float4 h0, h1;
-                act8(h4b + ((long)(c0 + b) * a.Np + sarg[b]) * 2048, pfmt, 8 * q, pfmt ? sus[b][q >> 5] : 1.f, h0, h1);
+                act8(h4b + ((long)(c0 + b) * a.Np + sarg[b]) * 2048, pfmt, 8 * q, pfmt ? sus[b][(8 * q) >> s.pcbs[4]] : 1.f, h0, h1);
                 acc0 = f4fma(sdg[b], h0, acc0);
                 acc1 = f4fma(sdg[b], h1, acc1);
             }
@@ -270,8 +270,8 @@ __global__ __launch_bounds__(256) void enc_bwd_gather_kernel(const HpEncBwdArgs 
         const long hrow = (long)b * a.Np + s.crit.pt[(long)b * 512 + u];
         float us4 = 1.f, usl = 1.f;
         if (pfmt) {
-            us4 = pexp_unscale(s.pexp[4][(hrow >> 7) * 2 + (lane >> 5)]);
-            if (hl) usl = pexp_unscale(s.pexp[hl][hrow >> 7]);
+            us4 = pexp_unscale(s.pexp[4][(hrow >> 7) * s.pncb[4] + ((8 * lane) >> s.pcbs[4])]);
+            if (hl) usl = pexp_unscale(s.pexp[hl][(hrow >> 7) * s.pncb[hl] + (hc8 >> s.pcbs[hl])]);
         }
         float4 h0, h1, g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
         act8(h4b + hrow * 2048, pfmt, 8 * lane, us4, h0, h1);

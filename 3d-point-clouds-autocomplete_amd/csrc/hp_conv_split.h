@@ -6,8 +6,8 @@
 //   [0, 1408)                   weight exponents e_w of layers 2..5 (128 + 256 + 512 + 512 rows)
 //   [HP_CS_HI_OFF, ...)         f16 pieces of W2..W5 (2 x 434176 halfs): per row and 32-deep k-tile [hi 32 | lo 32]
 //   [HP_CS_AMAX_OFF, ...)       max|h_l| per 128-row tile, layers 1..4, as float bits: 4 arrays of hp_conv_split_tiles_pad(R)
-//   [.. + 4 tp, ...)            round 4 (conv_pp.hip): block exponents of the P-format activations h1, h2, h3 (tp ints each: one per
-//                               128-row tile) and h4 (2 tp: two 256-channel blocks per tile), then the format word
+//   [.. + 4 tp, ...)            round 4 (conv_pp.hip): block exponents of the P-format activations h1..h4: 4 tp ints per layer
+//                               ([tile][column block], hp_conv_pp_ncb(l) blocks per 128-row tile in use), then the format word
 //                               (HP_PP_FMT_P while h1..h4 of this workspace hold P-format, else fp32) + 3 words of padding
 #define HP_CS_WEXP_OFF 0L
 #define HP_CS_HI_OFF 1408L
@@ -38,4 +38,6 @@ int hp_conv_pp_layer(int l, int n, const float* X, const float* bias, long sBias
 int hp_conv_pp_mark(int n, float* area0, long sWs, long R, int fmt, hipStream_t stream);
 int hp_conv_pp_unpack_ws(float* ws, long R, hipStream_t stream);
 // exponent table of P-format h_l (l = 1..4) inside the split area (ints), tp = hp_conv_split_tiles_pad(R)
-inline long hp_conv_pp_exp_offset(int l, long tp) { return HP_CS_AMAX_OFF + 4 * tp + (long)(l - 1) * tp; }
+inline long hp_conv_pp_exp_offset(int l, long tp) { return HP_CS_AMAX_OFF + 4 * tp + (long)(l - 1) * 4 * tp; }   // room for 4 column blocks per tile
+// column blocks per 128-row tile of P-format h_l (l = 1..4): the producing launch's column tiles (conv_pp.hip: launch_pp's choice)
+int hp_conv_pp_ncb(int l);

@@ -29,7 +29,8 @@ struct HpEncBwdSide {
     const float* h[5];       /* h[l] = the forward's per-point activations of layer l (l = 1..4), (B*Np, kEnc[l]): fp32, or — when
                                 *fmt == HP_PP_FMT_P — P-format lines [hi 32 | lo 32] f16 with block exponents pexp[l] (conv_pp.hip) */
     const int* fmt;          /* the forward workspace's format word */
-    const int* pexp[5];      /* pexp[l][(row >> 7) * ncb + block]: ncb = 1 for l = 1..3, 2 (256-channel blocks) for l = 4 */
+    const int* pexp[5];      /* pexp[l][(row >> 7) * pncb[l] + block]: pncb[l] column blocks of kEnc[l] / pncb[l] channels per 128-row tile */
+    int pncb[5], pcbs[5];    /* blocks per tile, log2 of a block's channels */
     /* VAE head (prep kernel): d mu = gz + gmu ; d lv = (gz*eps + gexplv) * exp(lv) */
     const float *eps, *lv, *gout, *gmu, *gexplv;
     float *dmu, *dlv;

@@ -950,7 +950,13 @@ int encoder_backward_fused(int B, int Np, int out_size, int n, const HpEncoderBw
             const long tp = hp_conv_split_tiles_pad(R);
             s.fmt = reinterpret_cast<const int*>(area + hp_conv_pp_fmt_offset(R));
             s.pexp[0] = nullptr;
-            for (int l = 1; l <= 4; ++l) s.pexp[l] = reinterpret_cast<const int*>(area + hp_conv_pp_exp_offset(l, tp));
+            for (int l = 1; l <= 4; ++l) {
+                s.pexp[l] = reinterpret_cast<const int*>(area + hp_conv_pp_exp_offset(l, tp));
+                s.pncb[l] = hp_conv_pp_ncb(l);
+                int sh = 0;
+                while ((kEnc[l] / s.pncb[l]) >> (sh + 1)) ++sh;
+                s.pcbs[l] = sh;
+            }
         }
         for (int l = 0; l < 5; ++l) {
             s.W[l] = e.w->conv_w[l];
