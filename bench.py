@@ -96,7 +96,7 @@ def event_time_ms(fn, iters, warm=2):
     return s.elapsed_time(e) / iters
 
 
-def roofline_dominant_kernel(batch, n_half):
+def roofline_dominant_kernel(batch, n_half, minimal=False):
     """The widest matrix kernel of the step: layer 5 of the encoders' conv stack with its fused max-pool,
     max over points of A(M x 512) W(512 x 512)^T + b, M = B*1024 points of one encoder (the step batches both encoders into one
     launch of twice the tiles: `paired_launch` times that shape too).  Round 3 moved the layer from the fp32 matrix pipe
@@ -119,6 +119,9 @@ def roofline_dominant_kernel(batch, n_half):
     # kernel of a training run executes in (tools/roof_sweep.py)
     pp = ops.GemmPP(a, w, b, relu=False, xcb=256, group_rows=n_half)
     ms = event_time_ms(lambda: pp.run(1), iters=100, warm=200)
+    if minimal:      # (the rocprofv3 passes of tools/final_measure.sh: only the kernel itself in the trace)
+        flops = 2.0 * m * 512 * 512
+        return {"kernel": "conv_pp_kernel<1, 2, 2>", "avg_launch_ms": round(ms, 4), "achieved": round(flops / (ms * 1e-3) / 1e12, 2)}
     a2 = torch.cat([a, a.flip(0)])
     pp2 = ops.GemmPP(a2, w, b, relu=False, xcb=256, group_rows=n_half)
     ms_pair = event_time_ms(lambda: pp2.run(1), iters=60, warm=100)
@@ -135,7 +138,7 @@ def roofline_dominant_kernel(batch, n_half):
         rec = json.load(open(pmc))
         if "conv_pp" in rec.get("kernel", ""):
             traffic = rec["hbm_bytes_per_launch"]
-    return {"bound": "mfma", "kernel": "conv_pp_kernel<1, 2> (encoder conv5 + fused max-pool: M=B*1024, N=K=512; both operands stored as "
+    return {"bound": "mfma", "kernel": "conv_pp_kernel<1, 2, 2> (encoder conv5 + fused max-pool: M=B*1024, N=K=512; both operands stored as "
                                        "2 f16 pieces and DMA-staged, 3 x v_mfma_f32_32x32x16_f16 per 32x32x16 block of products, fp32 "
                                        "accumulate)",
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
@@ -386,6 +389,15 @@ def roofline_emd(batch, n):
     out = {"bound": "valu-issue", "kernel": "hp_emd_forward = emd_rows1_kernel x9 + emd_rows2_kernel x9 + emd_grad2_kernel "
            f"(B={batch}, n=m={n}, grad2 + cost)", "avg_call_ms": round(ms, 4), "peak": round(PEAK_VALU_ISSUE_TCYC, 4),
            "unit": "T issue-cycles/s", "exp_per_call": 36.0 * batch * n * n}
+    # the ALGORITHMIC floor next to the issue-stream form: SURVEY 8(d) fixes 27 exponentials per point pair
+    # (approxmatch.cu:86,131,185: three phases x nine levels); v_exp_f32 is quarter-rate = 8 issue cycles per 64-lane
+    # wave-instruction.  The call executes 36 (the match-free path re-evaluates the nine of the last sweep).
+    alg_cyc = 27.0 * batch * n * n / 64.0 * 8.0
+    out["algorithmic"] = {"exp_per_pair": 27, "issue_cycles_per_call": alg_cyc,
+                          "frac": round(alg_cyc / (ms * 1e-3) / 1e12 / PEAK_VALU_ISSUE_TCYC, 4),
+                          "frac_of_executed_exp": round(36.0 / 27.0 * alg_cyc / (ms * 1e-3) / 1e12 / PEAK_VALU_ISSUE_TCYC, 4),
+                          "what": "exponentials alone (27 per pair, 8 issue cycles per wave-instruction) / time / (1024 SIMDs x 2.4 GHz); "
+                                  "frac_of_executed_exp prices the 36 per pair the match-free call executes"}
     if model and model.get("batch") == batch and model.get("n") == n:
         cyc = model["issue_cycles_per_call"]
         out.update({"achieved": round(cyc / (ms * 1e-3) / 1e12, 4), "frac": round(cyc / (ms * 1e-3) / 1e12 / PEAK_VALU_ISSUE_TCYC, 4),
@@ -487,6 +499,7 @@ def main():
     ap.add_argument("--no-emd", action="store_true", help="reference-faithful Chamfer-only loss as the headline step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline/breakdown side measurements")
+    ap.add_argument("--roofline-minimal", action="store_true", help="the roofline kernel alone (200 warm-up + 100 timed launches): the command of the rocprofv3 passes")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the roofline leg (the dominant kernel at the step's shape) and print its object: the "
                          "command profiles/ pairs with `rocprofv3 --kernel-trace --stats`")
@@ -497,6 +510,9 @@ def main():
         sys.exit(spawn_ranks(args.gpus))       # before anything here touches the GPU
     if args.rendezvous_only:
         rendezvous_only(args, int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")))
+        return
+    if args.roofline_minimal:
+        print(json.dumps({"roofline": roofline_dominant_kernel(args.batch, args.points // 2, minimal=True)}), flush=True)
         return
     if args.roofline_only:
         torch.cuda.set_device(0)

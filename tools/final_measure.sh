@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): the numbers and rocprof summaries committed under profiles/ (per round: HP_ROUND, default r03).
+# Runs on the GPU box (gpurun): the numbers and rocprof summaries committed under profiles/ (per round: HP_ROUND, default r04).
 : "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"
 R=$GRAFT_REPO_ROOT; O="$R/gpurun_out/final"; rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
@@ -13,15 +13,15 @@ prof() { d=$1; shift; timeout 600 rocprofv3 --kernel-trace --stats --output-form
 pmc() { d=$1; c=$2; shift; shift; timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/$d -- python3 $B "$@" > /dev/null 2>&1; }
 STEP="--steps 5 --warmup 2 --no-extras --no-cpu-baseline"
 prof step $STEP
-prof roof --roofline-only
+prof roof --roofline-minimal
 prof stress --workload chamfer-stress --steps 5 --warmup 2 --no-extras
 for c in FETCH_SIZE WRITE_SIZE; do
-  pmc roof_pmc_$c $c --roofline-only
+  pmc roof_pmc_$c $c --roofline-minimal
   pmc step_pmc_$c $c --steps 3 --warmup 1 --no-extras --no-cpu-baseline
   pmc stress_pmc_$c $c --workload chamfer-stress --steps 3 --warmup 1 --no-extras
 done
 BUSY="GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"
-pmc roof_pmc_BUSY "$BUSY" --roofline-only
+pmc roof_pmc_BUSY "$BUSY" --roofline-minimal
 pmc step_pmc_BUSY "$BUSY" --steps 3 --warmup 1 --no-extras --no-cpu-baseline
 pmc stress_pmc_BUSY "$BUSY" --workload chamfer-stress --steps 3 --warmup 1 --no-extras
 # keep only the small csv summaries

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""gpurun_out/final (tools/final_measure.sh) -> the round's summaries committed under profiles/ (HP_ROUND, default r03)."""
+"""gpurun_out/final (tools/final_measure.sh) -> the round's summaries committed under profiles/ (HP_ROUND, default r04)."""
 import csv, glob, json, os, shutil, subprocess, sys
 from collections import defaultdict
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 F = os.path.join(R, "gpurun_out", "final")
 P = os.path.join(R, "profiles")
 py = sys.executable
-RD = os.environ.get("HP_ROUND", "r03")
+RD = os.environ.get("HP_ROUND", "r04")
 RN = RD.lstrip("r0")
 
 
@@ -39,7 +39,7 @@ subprocess.check_call([py, summ, os.path.join(F, "step"), os.path.join(P, f"{RD}
                        f"Round {RN} — full step: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-extras "
                        "--no-cpu-baseline (B=64, Chamfer+EMD; 7 engine steps, nothing else in the trace)", "7"])
 subprocess.check_call([py, summ, os.path.join(F, "roof"), os.path.join(P, f"{RD}_roofline_kernel_stats.md"),
-                       f"Round {RN} — roofline launch alone: rocprofv3 --kernel-trace --stats -- python3 bench.py --roofline-only "
+                       f"Round {RN} — roofline launch alone: rocprofv3 --kernel-trace --stats -- python3 bench.py --roofline-minimal "
                        "(encoder conv5: M=65536, N=K=512; 200 warm-up + 100 timed launches, back to back)", "1"])
 subprocess.check_call([py, summ, os.path.join(F, "stress"), os.path.join(P, f"{RD}_chamfer_n8192_kernel_stats.md"),
                        f"Round {RN} — BASELINE configs[4] per-GPU shape: rocprofv3 --kernel-trace --stats -- python3 bench.py --workload "
@@ -53,20 +53,20 @@ subprocess.check_call([py, pm, os.path.join(P, f"{RD}_pmc_chamfer_n8192.md"),
                        os.path.join(F, "stress_pmc_FETCH_SIZE"), os.path.join(F, "stress_pmc_WRITE_SIZE"), os.path.join(F, "stress_pmc_BUSY")])
 
 # ---- dominant GEMM (roofline.traffic)
-k = "conv_split_kernel<false>"
+k = "conv_pp_kernel<1, 2, 2>"
 fe, n, _ = one("roof_pmc_FETCH_SIZE", k)
 wr, _, _ = one("roof_pmc_WRITE_SIZE", k)
 bu, _, us = one("roof_pmc_BUSY", k)
 rd = fe["FETCH_SIZE"] * 1024 * 2
 out = {
-    "kernel": "conv_split_kernel<false> (split-f16 MFMA 32x32x16 x3, encoder conv5 shape M=65536 N=512 K=512, plain C store)",
-    "command": "rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python3 bench.py --roofline-only   (one pass per "
+    "kernel": "conv_pp_kernel<1, 2, 2> (both operands as f16 piece pairs, DMA-staged; MFMA 32x32x16 x3; encoder conv5 + fused max-pool, M=65536 N=512 K=512)",
+    "command": "rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python3 bench.py --roofline-minimal   (one pass per "
                "counter group: FETCH_SIZE | WRITE_SIZE | GRBM_GUI_ACTIVE SQ_*; tools/final_measure.sh)",
     "launches_averaged": n, "FETCH_SIZE_KB_raw": round(fe["FETCH_SIZE"], 1),
     "FETCH_SIZE_correction": "x2 (gfx950 counts 128-B requests at 64 B: MI355X_MICROARCH.md §HBM)",
     "WRITE_SIZE_KB": round(wr["WRITE_SIZE"], 1), "hbm_read_bytes_corrected": int(rd),
     "hbm_write_bytes": int(wr["WRITE_SIZE"] * 1024), "hbm_bytes_per_launch": int(rd + wr["WRITE_SIZE"] * 1024),
-    "algorithmic_bytes_per_launch": (2 * 65536 * 512 + 512 * 512 + 512) * 4,
+    "algorithmic_bytes_per_launch": (65536 * 512 + 512 * 512 + 512 + 2 * 512 * 512) * 4,
     "GRBM_GUI_ACTIVE_sum_over_8_xcd": bu["GRBM_GUI_ACTIVE"], "SQ_VALU_MFMA_BUSY_CYCLES": bu["SQ_VALU_MFMA_BUSY_CYCLES"],
     "mfma_pipe_busy_frac": round(bu["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * bu["GRBM_GUI_ACTIVE"] / 8), 4),
     "mfma_pipe_busy_is": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles): the fraction of the f16 matrix pipe's cycles AT THE CLOCK THE CHIP HELD",
