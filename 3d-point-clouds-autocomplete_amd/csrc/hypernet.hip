@@ -21,7 +21,9 @@
 // gemm.hip; only dW — both operands contiguous along the lanes — streams well without it.
 #include "hp_common.h"
 #include "hp_model.h"
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -47,14 +49,10 @@ struct HeadsDw {
     int Kc, rows, r0, theta_ld, cols;
 };
 
-// 4 workgroups per CU (<= 128 VGPRs): the Adam epilogue is an HBM stream and needs the waves in flight
+// one wave, one 32-row x 128-column unit
 template <bool ADAM>
-__global__ __launch_bounds__(kHdThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void heads_dw_kernel(const HeadsDw a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ void heads_dw_unit(const HeadsDw& a, int row0, int c0, int lane) {
     const int i = lane & 31, h = lane >> 5;
-    const int row0 = blockIdx.y * kUnitRows;
-    const int c0 = (blockIdx.x * (kHdThreads / 64) + wave) * kUnitCols;
-    if (c0 >= a.cols) return;
     const bool row_ok = row0 + i < a.rows;
     const float* ap = a.dtheta + a.r0 + row0 + i;             // + k * theta_ld
     const float* bp = a.t5 + c0 + 4 * i;                      // + k * cols
@@ -138,6 +136,29 @@ __global__ __launch_bounds__(kHdThreads) __attribute__((amdgpu_waves_per_eu(4, 4
     }
 }
 
+// 4 workgroups per CU (<= 128 VGPRs): the Adam epilogue is an HBM stream and needs the waves in flight
+template <bool ADAM>
+__global__ __launch_bounds__(kHdThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void heads_dw_kernel(const HeadsDw a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = blockIdx.y * kUnitRows;
+    const int c0 = (blockIdx.x * (kHdThreads / 64) + wave) * kUnitCols;
+    if (c0 >= a.cols) return;
+    heads_dw_unit<ADAM>(a, row0, c0, lane);
+}
+
+// The same units walked by PERSISTENT 16-wave workgroups, one per CU (4 waves per SIMD is all a CU takes of this kernel), on
+// only `gridDim.x` of the 256 CUs: the pass is an HBM stream — ~190 CUs saturate it — and the CUs it leaves alone are where the
+// latency-built launches of the trunk's backward and the encoders' tails run meanwhile (round 4: the pass starts right behind
+// the heads' dX instead of behind the tails; no CU mask, no special stream: the footprint is the grid).
+template <bool ADAM>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void heads_dw_persist_kernel(const HeadsDw a, int units_x,
+                                                                                                         int units) {
+    const int lane = threadIdx.x & 63;
+    const int nw = gridDim.x * 16;
+    for (int u = blockIdx.x * 16 + (threadIdx.x >> 6); u < units; u += nw)
+        heads_dw_unit<ADAM>(a, (u / units_x) * kUnitRows, (u % units_x) * kUnitCols, lane);
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -170,7 +191,16 @@ HP_API int hp_hypernet_heads_dw_adam(int Kc, int rows, int r0, const float* dthe
     const double bc1 = 1.0 - std::pow((double)beta1, step), bc2 = 1.0 - std::pow((double)beta2, step);
     HeadsDw a{dtheta_all, t5_all, nullptr, {W_rows, m_rows, v_rows, beta1, beta2, eps, (float)((double)lr / bc1),
               (float)(1.0 / std::sqrt(bc2))}, nullptr, Kc, rows, r0, theta_ld, 2048};
-    const dim3 grid((2048 / kUnitCols + 3) / 4, (rows + kUnitRows - 1) / kUnitRows);
+    static const int kWgs = [] {
+        const char* e = getenv("HP_HEADS_WGS");       // persistent 16-wave workgroups (= CUs the pass occupies); 0: one 4-wave workgroup per 4 units
+        return e ? atoi(e) : 176;
+    }();
+    const int ux = 2048 / kUnitCols, uy = (rows + kUnitRows - 1) / kUnitRows;
+    if (kWgs > 0) {
+        hipLaunchKernelGGL(heads_dw_persist_kernel<true>, dim3(std::min(kWgs, (ux * uy + 15) / 16)), dim3(1024), 0, stream, a, ux, ux * uy);
+        HP_RETURN_LAST_ERROR();
+    }
+    const dim3 grid((ux + 3) / 4, uy);
     hipLaunchKernelGGL(heads_dw_kernel<true>, grid, dim3(kHdThreads), 0, stream, a);
     HP_RETURN_LAST_ERROR();
 }

@@ -1213,9 +1213,26 @@ HP_API int hp_hypernet_forward(int B, int in_size, const float* latent, const Hp
     HP_RETURN_LAST_ERROR();
 }
 
+namespace {
+int hypernet_backward_impl(int B, int in_size, const float* latent, const HpHyperWeights* w, const float* t, const float* grad_theta,
+                           int theta_ld, const HpHyperGrads* gr, float* grad_latent, float* ws, hipStream_t stream, hipStream_t after);
+}
 HP_API int hp_hypernet_backward(int B, int in_size, const float* latent, const HpHyperWeights* w, const float* t,
                                 const float* grad_theta, int theta_ld, const HpHyperGrads* gr, float* grad_latent, float* ws,
                                 hipStream_t stream) {
+    return hypernet_backward_impl(B, in_size, latent, w, t, grad_theta, theta_ld, gr, grad_latent, ws, stream, nullptr);
+}
+// ... with a second stream `after` ordered behind the LAST READER of the heads' weights (d t5 = d theta . W and its split-K
+// reduce): what the caller enqueues on `after` next — the in-place dW + Adam pass over those weights — starts there, beside the
+// trunk's backward launches, instead of behind the whole call.
+HP_API int hp_hypernet_backward_ordered(int B, int in_size, const float* latent, const HpHyperWeights* w, const float* t,
+                                        const float* grad_theta, int theta_ld, const HpHyperGrads* gr, float* grad_latent, float* ws,
+                                        hipStream_t stream, hipStream_t after) {
+    return hypernet_backward_impl(B, in_size, latent, w, t, grad_theta, theta_ld, gr, grad_latent, ws, stream, after);
+}
+namespace {
+int hypernet_backward_impl(int B, int in_size, const float* latent, const HpHyperWeights* w, const float* t, const float* grad_theta,
+                           int theta_ld, const HpHyperGrads* gr, float* grad_latent, float* ws, hipStream_t stream, hipStream_t after) {
     HP_CHECK_ARG(B > 0 && in_size > 0 && latent && w && t && grad_theta && gr && ws);
     const float* act[5];
     {
@@ -1259,6 +1276,7 @@ HP_API int hp_hypernet_backward(int B, int in_size, const float* latent, const H
                       hd ? dt[4] : nullptr, 2048));
         off += nh;
     }
+    if (after && after != stream) TRY(hp_order_streams(stream, after));      // the heads' weights have been read for the last time
     // trunk
     {
         const int sk = hp_skinny_enabled() ? trunk_backward_skinny(B, in_size, latent, w, act, dt, gr, grad_latent, p, stream) : -2;
@@ -1277,6 +1295,7 @@ HP_API int hp_hypernet_backward(int B, int in_size, const float* latent, const H
     }
     HP_RETURN_LAST_ERROR();
 }
+}  // namespace
 
 // Rows [r0, r0+rows) of the heads' weight gradient from factors gathered over the data-parallel ranks:
 //   dW_rows (rows x 2048) = dtheta_all[:, r0 : r0+rows]^T (rows x Kc) . t5_all (Kc x 2048),   Kc = sum of the ranks' batches.

@@ -116,6 +116,11 @@ class FusedHeadsAdam:
         self.ran = False           # the pass of the step in flight has been launched (step() then leaves the heads to it)
         import os
         self.defer = os.environ.get("HP_HEADS_ADAM_DEFER", "1") != "0"
+        # Round 4: the pass starts right behind the heads' dX inside the hypernetwork's backward (hp_hypernet_backward_ordered
+        # orders `self.stream` there) and occupies only part of the chip (hp_hypernet_heads_dw_adam: persistent workgroups), so
+        # that it streams under the trunk's backward and the encoders' tails — launches that leave HBM idle — instead of beside
+        # the encoders' gather launch, which is HBM-bound itself.  HP_HEADS_EARLY=0: behind the tails as in round 3.
+        self.early = self.stream is not None and os.environ.get("HP_HEADS_EARLY", "1") != "0"
 
     accepts = HeadsShard.accepts
 
@@ -139,7 +144,9 @@ class FusedHeadsAdam:
                 "backward(); for gradient accumulation, skipped steps or a second backward build FlatAdam(model, ..., "
                 "fuse_heads=False) / TrainEngine(..., fuse_heads_adam=False).")
         self._job = (grad_theta, t5)
-        if self.stream is None or not self.defer:
+        if self.early:
+            self._launch(self.stream)          # (the library has ordered the stream behind the heads' dX already)
+        elif self.stream is None or not self.defer:
             self.flush()
 
     def pending(self):

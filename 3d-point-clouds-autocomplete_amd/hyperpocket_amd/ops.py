@@ -339,8 +339,16 @@ class HyperNetFunction(Function):
             exch.begin(grad_theta, t[o5:o5 + B * 2048].view(B, 2048))
         grad_latent = torch.empty_like(latent) if ctx.needs_input_grad[0] else None
         ws = torch.empty((_long_fn("hp_hypernet_backward_workspace_floats", B),), dtype=torch.float32, device=dev)
-        call("hp_hypernet_backward", B, in_size, latent, ctypes.byref(w), t, grad_theta, grad_theta.size(1), ctypes.byref(gr),
-             grad_latent, ws, current_stream(dev))
+        # An exchange object with a stream of its own and `early` set (core/engine.py FusedHeadsAdam) gets that stream ordered
+        # behind the LAST READER of the heads' weights inside the call (d t5 = d theta . W): its in-place dW + Adam pass then
+        # starts beside the trunk's backward launches, on the CUs its persistent grid occupies.
+        early = external_dw and getattr(exch, "early", False) and getattr(exch, "stream", None) is not None
+        if early:
+            call("hp_hypernet_backward_ordered", B, in_size, latent, ctypes.byref(w), t, grad_theta, grad_theta.size(1),
+                 ctypes.byref(gr), grad_latent, ws, current_stream(dev), ctypes.c_void_p(exch.stream.cuda_stream))
+        else:
+            call("hp_hypernet_backward", B, in_size, latent, ctypes.byref(w), t, grad_theta, grad_theta.size(1), ctypes.byref(gr),
+                 grad_latent, ws, current_stream(dev))
         if external_dw and hasattr(exch, "finish"):
             # in-place consumers of the heads' weights (the fused dW + Adam pass) go behind the backward that reads them
             o5 = _long_fn("hp_hypernet_t5_offset", B)

@@ -306,6 +306,12 @@ long hp_hypernet_backward_workspace_floats(int B);
 int hp_hypernet_backward(int B, int in_size, const float* latent, const HpHyperWeights* w, const float* t,
                          const float* grad_theta, int theta_ld, const HpHyperGrads* grads, float* grad_latent /* or NULL */,
                          float* ws, hpStream_t stream);
+/* ... with a second stream `after` (may be NULL) ordered behind the last reader of the heads' weights inside the call (d t5 =
+ * d theta . W): an in-place update of those weights enqueued on `after` next (hp_hypernet_heads_dw_adam) starts beside the trunk's
+ * backward launches instead of behind the whole call. */
+int hp_hypernet_backward_ordered(int B, int in_size, const float* latent, const HpHyperWeights* w, const float* t,
+                                 const float* grad_theta, int theta_ld, const HpHyperGrads* grads, float* grad_latent /* or NULL */,
+                                 float* ws, hpStream_t stream, hpStream_t after);
 /* Data-parallel form of the heads' weight gradient (no counterpart in the reference, which has no distributed code:
  * SURVEY 8e).  grads->head_w[0] == NULL makes hp_hypernet_backward skip dW of the heads (bias gradients and d latent are
  * still produced); ranks then all-gather d theta (B x theta_ld) and t5 (B x 2048, hp_hypernet_t5_offset(B) floats into
