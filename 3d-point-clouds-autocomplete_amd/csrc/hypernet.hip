@@ -181,9 +181,10 @@ int hp_heads_dw_launch(int Kc, int rows, int r0, const float* dtheta, int theta_
 // gradient and torch.optim.Adam re-reads it).  Rows [r0, r0+rows) of the (theta_ld x 2048) heads matrix:
 //   g = dtheta_all[:, r0:r0+rows]^T . t5_all  (Kc clouds);  W, exp_avg, exp_avg_sq <- Adam(W, g)   (torch semantics, wd = 0)
 // W_rows / m_rows / v_rows point at row r0 of the respective (.., 2048) matrices.  The gradient itself is never written.
-HP_API int hp_hypernet_heads_dw_adam(int Kc, int rows, int r0, const float* dtheta_all, int theta_ld, const float* t5_all,
-                                     float* W_rows, float* m_rows, float* v_rows, float lr, float beta1, float beta2, float eps,
-                                     int step, hipStream_t stream) {
+namespace {
+int heads_dw_adam_impl(int Kc, int rows, int r0, const float* dtheta_all, int theta_ld, const float* t5_all, float* W_rows,
+                       float* m_rows, float* v_rows, float lr, float beta1, float beta2, float eps, int step, int cus,
+                       hipStream_t stream) {
     HP_CHECK_ARG(Kc > 0 && rows >= 0 && r0 >= 0 && r0 + rows <= theta_ld && step >= 1);
     if (rows == 0) return 0;
     HP_CHECK_ARG(dtheta_all && t5_all && W_rows && m_rows && v_rows && aligned16(t5_all) && aligned16(W_rows) &&
@@ -191,16 +192,32 @@ HP_API int hp_hypernet_heads_dw_adam(int Kc, int rows, int r0, const float* dthe
     const double bc1 = 1.0 - std::pow((double)beta1, step), bc2 = 1.0 - std::pow((double)beta2, step);
     HeadsDw a{dtheta_all, t5_all, nullptr, {W_rows, m_rows, v_rows, beta1, beta2, eps, (float)((double)lr / bc1),
               (float)(1.0 / std::sqrt(bc2))}, nullptr, Kc, rows, r0, theta_ld, 2048};
-    static const int kWgs = [] {
-        const char* e = getenv("HP_HEADS_WGS");       // persistent 16-wave workgroups (= CUs the pass occupies); 0: one 4-wave workgroup per 4 units
-        return e ? atoi(e) : 176;
-    }();
     const int ux = 2048 / kUnitCols, uy = (rows + kUnitRows - 1) / kUnitRows;
-    if (kWgs > 0) {
-        hipLaunchKernelGGL(heads_dw_persist_kernel<true>, dim3(std::min(kWgs, (ux * uy + 15) / 16)), dim3(1024), 0, stream, a, ux, ux * uy);
+    if (cus > 0) {
+        hipLaunchKernelGGL(heads_dw_persist_kernel<true>, dim3(std::min(cus, (ux * uy + 15) / 16)), dim3(1024), 0, stream, a, ux, ux * uy);
         HP_RETURN_LAST_ERROR();
     }
     const dim3 grid((ux + 3) / 4, uy);
     hipLaunchKernelGGL(heads_dw_kernel<true>, grid, dim3(kHdThreads), 0, stream, a);
     HP_RETURN_LAST_ERROR();
+}
+}  // namespace
+
+HP_API int hp_hypernet_heads_dw_adam(int Kc, int rows, int r0, const float* dtheta_all, int theta_ld, const float* t5_all,
+                                     float* W_rows, float* m_rows, float* v_rows, float lr, float beta1, float beta2, float eps,
+                                     int step, hipStream_t stream) {
+    return heads_dw_adam_impl(Kc, rows, r0, dtheta_all, theta_ld, t5_all, W_rows, m_rows, v_rows, lr, beta1, beta2, eps, step, 0, stream);
+}
+// The same pass as a BACKGROUND stream: persistent 16-wave workgroups on `cus` of the 256 CUs (0: the default, 176; environment
+// HP_HEADS_WGS overrides).  For a caller that runs it on a stream of its own beside latency-built launches which need the other
+// CUs (core/engine.py FusedHeadsAdam behind hp_hypernet_backward_ordered); alone on the chip it is slower than the plain form.
+HP_API int hp_hypernet_heads_dw_adam_bg(int Kc, int rows, int r0, const float* dtheta_all, int theta_ld, const float* t5_all,
+                                        float* W_rows, float* m_rows, float* v_rows, float lr, float beta1, float beta2, float eps,
+                                        int step, int cus, hipStream_t stream) {
+    static const int kWgs = [] {
+        const char* e = getenv("HP_HEADS_WGS");
+        return e ? atoi(e) : 176;
+    }();
+    const int use = cus > 0 ? cus : kWgs;
+    return heads_dw_adam_impl(Kc, rows, r0, dtheta_all, theta_ld, t5_all, W_rows, m_rows, v_rows, lr, beta1, beta2, eps, step, use, stream);
 }

@@ -159,9 +159,14 @@ class FusedHeadsAdam:
         dev = grad_theta.device
         self._keep, self._job = (grad_theta, t5), None      # alive until join(): the side stream reads them
         with torch.cuda.stream(st):
-            call("hp_hypernet_heads_dw_adam", grad_theta.size(0), self.rows, 0, grad_theta, grad_theta.size(1), t5,
-                 self.flat.flat[self.lo:self.lo + n], e.exp_avg[self.lo:self.lo + n], e.exp_avg_sq[self.lo:self.lo + n],
-                 float(e.lr), float(e.betas[0]), float(e.betas[1]), float(e.eps), int(e._adam_step), current_stream(dev))
+            if self.early and st is self.stream:      # beside the trunk's backward: the background form (part of the chip)
+                call("hp_hypernet_heads_dw_adam_bg", grad_theta.size(0), self.rows, 0, grad_theta, grad_theta.size(1), t5,
+                     self.flat.flat[self.lo:self.lo + n], e.exp_avg[self.lo:self.lo + n], e.exp_avg_sq[self.lo:self.lo + n],
+                     float(e.lr), float(e.betas[0]), float(e.betas[1]), float(e.eps), int(e._adam_step), 0, current_stream(dev))
+            else:
+                call("hp_hypernet_heads_dw_adam", grad_theta.size(0), self.rows, 0, grad_theta, grad_theta.size(1), t5,
+                     self.flat.flat[self.lo:self.lo + n], e.exp_avg[self.lo:self.lo + n], e.exp_avg_sq[self.lo:self.lo + n],
+                     float(e.lr), float(e.betas[0]), float(e.betas[1]), float(e.eps), int(e._adam_step), current_stream(dev))
         self.ran = True
 
     def launch_ordered(self):

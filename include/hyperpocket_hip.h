@@ -329,6 +329,11 @@ int hp_hypernet_heads_dw_rows(int Kc, int rows, int r0, const float* dtheta_all,
 int hp_hypernet_heads_dw_adam(int Kc, int rows, int r0, const float* dtheta_all, int theta_ld, const float* t5_all,
                               float* W_rows, float* m_rows, float* v_rows, float lr, float beta1, float beta2, float eps,
                               int step, hpStream_t stream);
+/* ... as a BACKGROUND stream: persistent 16-wave workgroups on `cus` of the 256 CUs (0: 176; environment HP_HEADS_WGS) — for a caller
+ * that runs the pass on its own stream beside latency-built launches which need the other CUs.  Same results. */
+int hp_hypernet_heads_dw_adam_bg(int Kc, int rows, int r0, const float* dtheta_all, int theta_ld, const float* t5_all,
+                                 float* W_rows, float* m_rows, float* v_rows, float lr, float beta1, float beta2, float eps,
+                                 int step, int cus, hpStream_t stream);
 
 /* The M = B <= 64 chains (hypernetwork trunk, encoder fc/mu/std tail) run as skinny layer programs — ONE latency-built
  * launch per phase (layer), ordered by the kernel boundary, no reduce launches: csrc/skinny.hip; the one-persistent-launch
