@@ -33,6 +33,7 @@
 #include "hp_common.h"
 #include "hp_enc_bwd.h"
 #include "hp_conv_split.h"
+#include "hp_enc_bwd_wprep.h"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -113,6 +114,10 @@ __global__ __launch_bounds__(512) void enc_bwd_prep_kernel(const HpEncBwdArgs a)
     __shared__ int scan[512];
     const HpEncBwdSide& s = a.e[blockIdx.y];
     const int b = blockIdx.x, t = threadIdx.x;
+    if (b >= a.B) {      // the f16 chain's weight stream (enc_bwd_f16.hip): 14 workgroups behind the clouds'
+        hp_wprep::task(s, b - a.B, t);
+        return;
+    }
     if (s.is_vae && t < a.out) {   // model/encoder.py:38-41,49-51: z = eps*exp(lv) + mu, returned "logvar" = exp(lv)
         const long i = (long)b * a.out + t;
         const float gz = s.gout ? s.gout[(long)b * s.gout_ld + t] : 0.f;
@@ -260,6 +265,8 @@ __global__ __launch_bounds__(256) void enc_bwd_gather_kernel(const HpEncBwdArgs 
             const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
             *reinterpret_cast<float4*>(dst) = zero;
             *reinterpret_cast<float4*>(dst + 4) = zero;
+            if (lane == 0) s.d4max[crow] = 0.f;
+            s.hmask[crow * 64 + lane] = 0;
             if (hl) {
                 *reinterpret_cast<float4*>(hdst) = zero;
                 *reinterpret_cast<float4*>(hdst + 4) = zero;
@@ -297,12 +304,24 @@ __global__ __launch_bounds__(256) void enc_bwd_gather_kernel(const HpEncBwdArgs 
                     a1 = f4fma(g[k], w1[k], a1);
                 }
         }
-        *reinterpret_cast<float4*>(dst) = f4mask(h0, a0);
-        *reinterpret_cast<float4*>(dst + 4) = f4mask(h1, a1);
+        a0 = f4mask(h0, a0);
+        a1 = f4mask(h1, a1);
+        *reinterpret_cast<float4*>(dst) = a0;
+        *reinterpret_cast<float4*>(dst + 4) = a1;
+        {   // the row's maximum: the f16 chain's scale (enc_bwd_f16.hip)
+            float m = fmaxf(fmaxf(fmaxf(fabsf(a0.x), fabsf(a0.y)), fmaxf(fabsf(a0.z), fabsf(a0.w))),
+                            fmaxf(fmaxf(fabsf(a1.x), fabsf(a1.y)), fmaxf(fabsf(a1.z), fabsf(a1.w))));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            if (lane == 0) s.d4max[crow] = m;
+        }
         if (hl) {
             *reinterpret_cast<float4*>(hdst) = g0;
             *reinterpret_cast<float4*>(hdst + 4) = g1;
         }
+        // the ReLU masks of the row as bits (lanes 56..63: padding): byte `lane` = the lane's 8 channels
+        s.hmask[crow * 64 + lane] = (unsigned char)((g0.x > 0.f) | (g0.y > 0.f) << 1 | (g0.z > 0.f) << 2 | (g0.w > 0.f) << 3 |
+                                                    (g1.x > 0.f) << 4 | (g1.y > 0.f) << 5 | (g1.z > 0.f) << 6 | (g1.w > 0.f) << 7);
     }
 }
 
@@ -848,7 +867,8 @@ void prof_tasks(const char* name, long n, int types, const char* const* nm, hipS
 }  // namespace
 
 int hp_enc_bwd_prep(const HpEncBwdArgs* a, hipStream_t stream) {
-    hipLaunchKernelGGL(enc_bwd_prep_kernel, dim3(a->B, a->n), dim3(512), 0, stream, *a);
+    const int extra = hp_enc_bwd_chain_f16_enabled() ? hp_wprep::kTasks : 0;
+    hipLaunchKernelGGL(enc_bwd_prep_kernel, dim3(a->B + extra, a->n), dim3(512), 0, stream, *a);
     HP_RETURN_LAST_ERROR();
 }
 
@@ -870,8 +890,14 @@ int hp_enc_bwd_conv(const HpEncBwdArgs* a0, hipStream_t stream) {
         static const char* const nm[] = {"", "dW5", "delta4-rows"};
         prof_tasks("gather", ngat, 2, nm, stream);
     }
-    arm(nblk, 10);
-    hipLaunchKernelGGL(enc_bwd_chain_kernel, dim3((unsigned)nblk), dim3(kChainThreads), 0, stream, *a);
+    const bool chain16 = hp_enc_bwd_chain_f16_enabled() && !prof_on;
+    if (chain16) {
+        const int rc = hp_enc_bwd_chain_f16(a, stream);
+        if (rc) return rc;
+    } else {
+        arm(nblk, 10);
+        hipLaunchKernelGGL(enc_bwd_chain_kernel, dim3((unsigned)nblk), dim3(kChainThreads), 0, stream, *a);
+    }
     if (prof_on) {
         (void)hipStreamSynchronize(stream);
         std::vector<long long> hb(10 * nblk);

@@ -19,6 +19,9 @@ struct HpCrit {
 /* partial-sum layout of one row range: [dW4 | dW3 | dW2 | dW1 | db4 | db3 | db2 | db1] */
 #define HP_EB_PART_FLOATS (512 * 256 + 256 * 128 + 128 * 64 + 64 * 3 + 512 + 256 + 128 + 64)
 #define HP_EB_MAX_SPLITS 64
+/* enc_bwd_f16.hip: W4, W3, W2 as the chain's A-fragment stream (42 chunks of 16 KB) + the 2^-e table of their columns */
+#define HP_EB_WT_BYTES (42L * 16384)
+#define HP_EB_WT_US_FLOATS (256 + 128 + 64)
 
 struct HpEncBwdSide {
     /* inputs */
@@ -40,6 +43,10 @@ struct HpEncBwdSide {
     float* d[5];             /* d[l], l = 1..4 */
     float* hc[4];            /* hc[0] = xc (3 per row), hc[1..3] */
     float* part;             /* S * HP_EB_PART_FLOATS partial sums */
+    float* d4max;            /* max |delta4[row][:]| of every row the gather launch writes (the f16 chain's row scale) */
+    unsigned char* hmask;    /* 64 bytes per row: bit c of bytes [0,32) = (h3[row][c] > 0), [32,48) h2, [48,56) h1 (gather launch) */
+    unsigned char* wt;       /* HP_EB_WT_BYTES: the f16 chain's weight stream (prep launch) */
+    float* wt_us;            /* HP_EB_WT_US_FLOATS */
     float* gW[5];            /* d conv_w[l-1], l = 1..5 */
     float* gb[5];
 };
@@ -53,5 +60,8 @@ struct HpEncBwdArgs {
 #ifdef __cplusplus
 int hp_enc_bwd_prep(const HpEncBwdArgs* a, hipStream_t stream);      /* sort + VAE head */
 int hp_enc_bwd_conv(const HpEncBwdArgs* a, hipStream_t stream);      /* gather + chain + dW + reduce */
+int hp_enc_bwd_chain_f16(const HpEncBwdArgs* a, hipStream_t stream); /* enc_bwd_f16.hip: weight stream + delta chain on the f16 pipe */
+bool hp_enc_bwd_chain_f16_enabled();                                  /* HP_EB_CHAIN16 (default on) / hp_enc_bwd_chain_f16_set */
+int hp_enc_bwd_chain_f16_set(int on);
 int hp_enc_bwd_max_clouds();                                          /* largest B the dW launch's LDS table serves */
 #endif

@@ -433,7 +433,8 @@ __global__ __launch_bounds__(256) void vae_head_bwd_kernel(long n, const float* 
 long enc_fwd_ws(long B, long Np) { return B * Np * (64 + 128 + 256 + 512 + 512) + hp_conv_split_area_floats(B * Np); }
 long enc_bwd_ws(long B, long out) {
     const long Rc = B * 512;
-    return Rc * 4 + Rc * (64 + 128 + 256 + 512) * 2 + B * (2 * out + 4 * 512) + kSplitWs + 64 + (B * (5 * 512 + 4) + 16);
+    return Rc * 4 + Rc * (64 + 128 + 256 + 512) * 2 + B * (2 * out + 4 * 512) + kSplitWs + 64 + (B * (5 * 512 + 4) + 16) +
+           Rc * 17 + HP_EB_WT_BYTES / 4 + HP_EB_WT_US_FLOATS + 16;      // (row maxima, row masks, weight stream: enc_bwd_f16.hip)
 }
 
 
@@ -750,6 +751,7 @@ struct EncBwdWs {
     float* dl[5];
     float *dmu, *dlv, *tmp, *dfc, *dg, *split;
     Crit crit;
+    float *d4max, *hmask, *wt, *wt_us;      // enc_bwd_f16.hip
 };
 EncBwdWs enc_bwd_layout(float* ws, long B, long out_size) {
     const long Rc = B * 512;
@@ -774,6 +776,10 @@ EncBwdWs enc_bwd_layout(float* ws, long B, long out_size) {
     L.crit.cnt = L.crit.eslot + B * 512;
     L.crit.off = L.crit.cnt + B;
     L.crit.total = L.crit.off + B;
+    L.d4max = take(Rc);
+    L.hmask = take(Rc * 16);
+    L.wt = take(HP_EB_WT_BYTES / 4);
+    L.wt_us = take(HP_EB_WT_US_FLOATS);
     return L;
 }
 }  // namespace
@@ -970,6 +976,10 @@ int encoder_backward_fused(int B, int Np, int out_size, int n, const HpEncoderBw
         s.hc[0] = L[z].xc;
         for (int l = 1; l <= 3; ++l) s.hc[l] = L[z].hc[l];
         s.part = L[z].hc[4];                      // (B*512 x 512 floats; the fused path never gathers h4)
+        s.d4max = L[z].d4max;
+        s.hmask = reinterpret_cast<unsigned char*>(L[z].hmask);
+        s.wt = reinterpret_cast<unsigned char*>(L[z].wt);
+        s.wt_us = L[z].wt_us;
         const float* dmu_p = e.is_vae ? L[z].dmu : e.grad_out;
         const int dmu_ld = e.is_vae ? out_size : e.grad_out_ld;
         t[z] = EncTailBwd{e.g, e.f, e.w, dmu_p, dmu_ld, e.is_vae ? L[z].dlv : nullptr, e.gr, L[z].dfc, L[z].dg, L[z].split};
@@ -1035,6 +1045,9 @@ HP_API int hp_encoder_backward_set_fused(int on) {
     enc_bwd_fused_flag() = on != 0;
     return prev;
 }
+// Test switch for the fused backward's delta chain: 1 (default; HP_EB_CHAIN16) = the f16 matrix pipe with split operands
+// (enc_bwd_f16.hip), 0 = round 3's fp32 MFMA chain (enc_bwd.hip), -1 = back to the environment's choice.  Returns the previous setting.
+HP_API int hp_encoder_backward_set_chain_f16(int on) { return hp_enc_bwd_chain_f16_set(on); }
 // Both encoders of a HyperPocket step in one call (io[0], io[1]: hp_encoder_backward_ld's arguments as structs; same B, Np,
 // out_size), on ONE stream: the two conv stacks share the prep / chain / dW / reduce launches, the two tails three skinny
 // launches.  Results are those of two hp_encoder_backward_ld calls, bit for bit.

@@ -13,7 +13,7 @@
  *      approxmatch.cu:334-337; its nndistance launchers check nothing, nndistance.cu:131-160).
  * Layouts are the reference's: point sets (b, n, 3) fp32 contiguous, indices int32.
  *
- * TEST HOOKS.  hp_emd_set_rows_per_lane, hp_encoder_backward_set_fused, hp_conv_split_set, hp_skinny_set_enabled,
+ * TEST HOOKS.  hp_emd_set_rows_per_lane, hp_encoder_backward_set_fused, hp_encoder_backward_set_chain_f16, hp_conv_split_set, hp_skinny_set_enabled,
  * hp_target_fused_set_f16 (and hp_conv_presplit_set below) flip PROCESS-WIDE switches that select between implementations of
  * the same result; they exist so that the parity tests can hold every implementation against the oracle in one process.  They
  * are plain globals: not thread-safe, not per-stream, not meant to be called while another host thread is inside the library.
@@ -284,6 +284,11 @@ int hp_encoder_backward_pair_ordered(int B, int Np, int out_size, const HpEncode
  * Returns the previous setting. */
 /* [test hook: process-wide, not thread-safe — see the header comment] */
 int hp_encoder_backward_set_fused(int on);
+/* The fused backward's delta chain (delta4 -> delta1 of the critical rows) runs on the f16 matrix pipe with split fp32 operands
+ * (csrc/enc_bwd_f16.hip; environment HP_EB_CHAIN16, default 1); 0 selects round 3's fp32 MFMA chain, -1 the environment's choice.
+ * Returns the previous setting (-1: never set). */
+/* [test hook: process-wide, not thread-safe — see the header comment] */
+int hp_encoder_backward_set_chain_f16(int on);
 /* The encoders' conv stack (model/encoder.py:14-28) runs on the f16 matrix pipe with every fp32 operand split into two
  * f16 pieces (three MFMA products per block; as close to fp64 as the fp32 fma chain — csrc/conv_split.hip).  0 sends it
  * through the fp32 MFMA GEMMs instead (also: environment HP_CONV_SPLIT=0).  Returns the previous setting. */
