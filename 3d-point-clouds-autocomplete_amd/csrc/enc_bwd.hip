@@ -39,6 +39,8 @@
 #include <cstdlib>
 #include <vector>
 
+bool hp_enc_bwd_dw_f16_enabled();
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -266,6 +268,7 @@ __global__ __launch_bounds__(256) void enc_bwd_gather_kernel(const HpEncBwdArgs 
             *reinterpret_cast<float4*>(dst) = zero;
             *reinterpret_cast<float4*>(dst + 4) = zero;
             if (lane == 0) s.d4max[crow] = 0.f;
+            if (lane < 4) s.hmax[crow * 4 + lane] = 0.f;
             s.hmask[crow * 64 + lane] = 0;
             if (hl) {
                 *reinterpret_cast<float4*>(hdst) = zero;
@@ -318,6 +321,17 @@ __global__ __launch_bounds__(256) void enc_bwd_gather_kernel(const HpEncBwdArgs 
         if (hl) {
             *reinterpret_cast<float4*>(hdst) = g0;
             *reinterpret_cast<float4*>(hdst + 4) = g1;
+        }
+        {   // maxima of the row's h3 (lanes 0..31), h2 (32..47), h1 (48..55): the f16 dW launch's block scales
+            float m = fmaxf(fmaxf(fmaxf(g0.x, g0.y), fmaxf(g0.z, g0.w)), fmaxf(fmaxf(g1.x, g1.y), fmaxf(g1.z, g1.w)));
+            m = fmaxf(m, __shfl_xor(m, 1, 64));
+            m = fmaxf(m, __shfl_xor(m, 2, 64));
+            m = fmaxf(m, __shfl_xor(m, 4, 64));
+            const float m8 = fmaxf(m, __shfl_xor(m, 8, 64));
+            m = lane < 48 ? m8 : m;
+            const float m16 = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = lane < 32 ? m16 : m;
+            if (lane == 0 || lane == 32 || lane == 48) s.hmax[crow * 4 + (lane == 0 ? 0 : (lane == 32 ? 1 : 2))] = m;
         }
         // the ReLU masks of the row as bits (lanes 56..63: padding): byte `lane` = the lane's 8 channels
         s.hmask[crow * 64 + lane] = (unsigned char)((g0.x > 0.f) | (g0.y > 0.f) << 1 | (g0.z > 0.f) << 2 | (g0.w > 0.f) << 3 |
@@ -873,6 +887,13 @@ int hp_enc_bwd_prep(const HpEncBwdArgs* a, hipStream_t stream) {
 }
 
 int hp_enc_bwd_max_clouds() { return kMaxClouds; }
+bool hp_enc_bwd_dw_f16_enabled() {      // HP_EB_DW16 (default on): the dW launch on the f16 pipe (needs the f16 chain's block exponents)
+    static const bool on = [] {
+        const char* e = getenv("HP_EB_DW16");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
 
 int hp_enc_bwd_conv(const HpEncBwdArgs* a0, hipStream_t stream) {
     HpEncBwdArgs args = *a0;
@@ -933,8 +954,13 @@ int hp_enc_bwd_conv(const HpEncBwdArgs* a0, hipStream_t stream) {
                 "L2 %.1f(%.1f)\n", live, (double)(tmax - tmin) * 0.01, sum[0] / live, mx[0], sum[1] / live, mx[1], sum[2] / live, mx[2],
                 sum[3] / live, mx[3], sum[4] / live, mx[4]);
     }
-    arm(ndw, 4);
-    hipLaunchKernelGGL(enc_bwd_dw_kernel, dim3((unsigned)ndw), dim3(256), 0, stream, *a);
+    if (chain16 && hp_enc_bwd_dw_f16_enabled()) {
+        const int rc = hp_enc_bwd_dw_f16(a, stream);
+        if (rc) return rc;
+    } else {
+        arm(ndw, 4);
+        hipLaunchKernelGGL(enc_bwd_dw_kernel, dim3((unsigned)ndw), dim3(256), 0, stream, *a);
+    }
     if (prof_on) {
         static const char* const nm[] = {"", "dW4", "dW3", "dW2+dW1"};
         prof_tasks("dw", ndw, 3, nm, stream);

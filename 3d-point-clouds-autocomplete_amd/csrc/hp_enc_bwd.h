@@ -44,6 +44,8 @@ struct HpEncBwdSide {
     float* hc[4];            /* hc[0] = xc (3 per row), hc[1..3] */
     float* part;             /* S * HP_EB_PART_FLOATS partial sums */
     float* d4max;            /* max |delta4[row][:]| of every row the gather launch writes (the f16 chain's row scale) */
+    float* hmax;             /* 4 per row: max of h3 / h2 / h1 of the row (gather launch), pad */
+    int* bexp;               /* 8 per 32-row block: scale exponents of delta4..delta1, h3..h1 (f16 chain launch, for the f16 dW launch) */
     unsigned char* hmask;    /* 64 bytes per row: bit c of bytes [0,32) = (h3[row][c] > 0), [32,48) h2, [48,56) h1 (gather launch) */
     unsigned char* wt;       /* HP_EB_WT_BYTES: the f16 chain's weight stream (prep launch) */
     float* wt_us;            /* HP_EB_WT_US_FLOATS */
@@ -60,6 +62,7 @@ struct HpEncBwdArgs {
 #ifdef __cplusplus
 int hp_enc_bwd_prep(const HpEncBwdArgs* a, hipStream_t stream);      /* sort + VAE head */
 int hp_enc_bwd_conv(const HpEncBwdArgs* a, hipStream_t stream);      /* gather + chain + dW + reduce */
+int hp_enc_bwd_dw_f16(const HpEncBwdArgs* a, hipStream_t stream);    /* enc_bwd_f16.hip: dW4..dW1, db4..db1 partial sums on the f16 pipe */
 int hp_enc_bwd_chain_f16(const HpEncBwdArgs* a, hipStream_t stream); /* enc_bwd_f16.hip: weight stream + delta chain on the f16 pipe */
 bool hp_enc_bwd_chain_f16_enabled();                                  /* HP_EB_CHAIN16 (default on) / hp_enc_bwd_chain_f16_set */
 int hp_enc_bwd_chain_f16_set(int on);

@@ -434,7 +434,7 @@ long enc_fwd_ws(long B, long Np) { return B * Np * (64 + 128 + 256 + 512 + 512) 
 long enc_bwd_ws(long B, long out) {
     const long Rc = B * 512;
     return Rc * 4 + Rc * (64 + 128 + 256 + 512) * 2 + B * (2 * out + 4 * 512) + kSplitWs + 64 + (B * (5 * 512 + 4) + 16) +
-           Rc * 17 + HP_EB_WT_BYTES / 4 + HP_EB_WT_US_FLOATS + 16;      // (row maxima, row masks, weight stream: enc_bwd_f16.hip)
+           Rc * 21 + B * 128 + HP_EB_WT_BYTES / 4 + HP_EB_WT_US_FLOATS + 32;      // (row maxima, row masks, weight stream: enc_bwd_f16.hip)
 }
 
 
@@ -751,7 +751,7 @@ struct EncBwdWs {
     float* dl[5];
     float *dmu, *dlv, *tmp, *dfc, *dg, *split;
     Crit crit;
-    float *d4max, *hmask, *wt, *wt_us;      // enc_bwd_f16.hip
+    float *d4max, *hmask, *hmax, *bexp, *wt, *wt_us;      // enc_bwd_f16.hip
 };
 EncBwdWs enc_bwd_layout(float* ws, long B, long out_size) {
     const long Rc = B * 512;
@@ -778,6 +778,8 @@ EncBwdWs enc_bwd_layout(float* ws, long B, long out_size) {
     L.crit.total = L.crit.off + B;
     L.d4max = take(Rc);
     L.hmask = take(Rc * 16);
+    L.hmax = take(Rc * 4);
+    L.bexp = take(B * 16 * 8);
     L.wt = take(HP_EB_WT_BYTES / 4);
     L.wt_us = take(HP_EB_WT_US_FLOATS);
     return L;
@@ -938,7 +940,10 @@ int order_behind(hipStream_t stream, hipStream_t after) {
 int encoder_backward_fused(int B, int Np, int out_size, int n, const HpEncoderBwdIO* io, hipStream_t stream, hipStream_t after) {
     HpEncBwdArgs a{};
     a.n = n; a.B = B; a.Np = Np; a.out = out_size;
-    a.S = std::max(1, std::min(B, std::min(env_int("HP_EB_SPLITS", 23), HP_EB_MAX_SPLITS)));   // S <= B: the h4 slot holds the partials
+    // row ranges of the dW launch.  f16 launch (enc_bwd_f16.hip): 12 workgroups per (encoder, range) group, a group on ONE XCD,
+    // two workgroups per CU -> 5 groups = 60 of an XCD's 64 slots, 40 groups on the chip: one round (46 groups ran as two).
+    const int dflt_splits = hp_enc_bwd_chain_f16_enabled() ? 40 / n : 23;
+    a.S = std::max(1, std::min(B, std::min(env_int("HP_EB_SPLITS", dflt_splits), HP_EB_MAX_SPLITS)));   // S <= B: the h4 slot holds the partials
     EncBwdWs L[2];
     EncTailBwd t[2];
     bool skinny_ok = hp_skinny_enabled() && B <= 64;
@@ -978,6 +983,8 @@ int encoder_backward_fused(int B, int Np, int out_size, int n, const HpEncoderBw
         s.part = L[z].hc[4];                      // (B*512 x 512 floats; the fused path never gathers h4)
         s.d4max = L[z].d4max;
         s.hmask = reinterpret_cast<unsigned char*>(L[z].hmask);
+        s.hmax = L[z].hmax;
+        s.bexp = reinterpret_cast<int*>(L[z].bexp);
         s.wt = reinterpret_cast<unsigned char*>(L[z].wt);
         s.wt_us = L[z].wt_us;
         const float* dmu_p = e.is_vae ? L[z].dmu : e.grad_out;
