@@ -76,6 +76,13 @@ typedef struct HpHyperGrads {
 #ifdef __cplusplus
 /* hypernet.hip (internal): fragment-direct heads kernels */
 bool hp_heads_dw_fast_ok(int cols, const float* t5, const float* out);
+/* heads_fwd.hip: the heads' forward at B <= 64 as a streaming bf16-pipe kernel */
+bool hp_heads_fwd_enabled();
+int hp_heads_fwd_set(int on);
+long hp_heads_fwd_ws_floats();
+bool hp_heads_fwd_ok(int B, int N, int K, const float* t5, const float* W, const float* ws);
+int hp_heads_fwd(int B, int N, const float* t5, const float* W, const float* bias, float* theta, int theta_ld, float* ws,
+                 hipStream_t stream);
 int hp_heads_dw_launch(int Kc, int rows, int r0, const float* dtheta, int theta_ld, const float* t5, int cols, float* dW,
                        float* db, hipStream_t stream);
 #endif

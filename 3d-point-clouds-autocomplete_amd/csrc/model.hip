@@ -1196,6 +1196,10 @@ int trunk_backward_skinny(int B, int in_size, const float* latent, const HpHyper
 HP_API long hp_hypernet_saved_floats(int B) { return (long)B * (64 + 128 + 512 + 1024 + 2048) + kSplitWs + 64; }
 HP_API long hp_hypernet_backward_workspace_floats(int B) { return (long)B * (64 + 128 + 512 + 1024 + 2048) + kSplitWs + 64; }
 
+// Test switch: the heads' forward as the streaming bf16-pipe kernel (1, default; HP_HEADS_FWD) or as the tiled fp32 GEMM (0);
+// -1 = the environment's choice.  Returns the previous setting.
+HP_API int hp_hypernet_set_heads_stream(int on) { return hp_heads_fwd_set(on); }
+
 // model/hyper_network.py:41-43.  t: saved trunk activations (hp_hypernet_saved_floats), theta (B, theta_ld)
 HP_API int hp_hypernet_forward(int B, int in_size, const float* latent, const HpHyperWeights* w, float* t, float* theta,
                                int theta_ld, hipStream_t stream) {
@@ -1220,8 +1224,12 @@ HP_API int hp_hypernet_forward(int B, int in_size, const float* latent, const Hp
     for (int hd = 0; hd < w->n_heads; ++hd) total += w->head_out[hd];
     HP_CHECK_ARG(total <= theta_ld);
     if (heads_contiguous(w->head_w, w->head_b, w->head_out, w->n_heads)) {
-        // the heads' weights form one (total x 2048) matrix (FlatParameters lays them out back to back): one GEMM
-        TRY(op.lin_fwd(in, 0, 2048, w->head_w[0], 0, w->head_b[0], 0, theta, 0, theta_ld, B, total, 2048, 1, false));
+        // the heads' weights form one (total x 2048) matrix (FlatParameters lays them out back to back): one launch — the
+        // streaming bf16-pipe kernel of heads_fwd.hip for B <= 64 (its t5 pieces go where the GEMM's split-K slabs would), else one GEMM
+        if (hp_heads_fwd_enabled() && hp_heads_fwd_ws_floats() <= kSplitWs && hp_heads_fwd_ok(B, total, 2048, in, w->head_w[0], op.splitws))
+            TRY(hp_heads_fwd(B, total, in, w->head_w[0], w->head_b[0], theta, theta_ld, op.splitws, stream));
+        else
+            TRY(op.lin_fwd(in, 0, 2048, w->head_w[0], 0, w->head_b[0], 0, theta, 0, theta_ld, B, total, 2048, 1, false));
     } else {
         int off = 0;
         for (int hd = 0; hd < w->n_heads; ++hd) {

@@ -13,7 +13,7 @@
  *      approxmatch.cu:334-337; its nndistance launchers check nothing, nndistance.cu:131-160).
  * Layouts are the reference's: point sets (b, n, 3) fp32 contiguous, indices int32.
  *
- * TEST HOOKS.  hp_emd_set_rows_per_lane, hp_encoder_backward_set_fused, hp_encoder_backward_set_chain_f16, hp_conv_split_set, hp_skinny_set_enabled,
+ * TEST HOOKS.  hp_emd_set_rows_per_lane, hp_encoder_backward_set_fused, hp_encoder_backward_set_chain_f16, hp_hypernet_set_heads_stream, hp_conv_split_set, hp_skinny_set_enabled,
  * hp_target_fused_set_f16 (and hp_conv_presplit_set below) flip PROCESS-WIDE switches that select between implementations of
  * the same result; they exist so that the parity tests can hold every implementation against the oracle in one process.  They
  * are plain globals: not thread-safe, not per-stream, not meant to be called while another host thread is inside the library.
@@ -302,6 +302,11 @@ long hp_gemm_f16x2_workspace_floats(long M, int N, int K);
 int hp_gemm_f16x2_prepare(long M, int N, int K, const float* X, const float* W, float* ws, hpStream_t stream);
 int hp_gemm_f16x2_run(long M, int N, int K, const float* X, const float* bias, float* C, int relu, const float* ws, hpStream_t stream);
 
+/* The heads' forward (theta = t5 . W^T + b at B <= 64, 156 MB of weights) runs as a streaming kernel on the bf16 matrix pipe with
+ * every fp32 operand split into three bf16 pieces (exact split, six products: csrc/heads_fwd.hip; environment HP_HEADS_FWD,
+ * default 1); 0 selects the tiled fp32 GEMM + split-K reduce, -1 the environment's choice.  Returns the previous setting. */
+/* [test hook: process-wide, not thread-safe — see the header comment] */
+int hp_hypernet_set_heads_stream(int on);
 /* HyperNetwork.forward (model/hyper_network.py:41-43): latent (B,in) -> theta (B,theta_ld); t = saved trunk
  * activations (hp_hypernet_saved_floats floats) for the backward. */
 long hp_hypernet_saved_floats(int B);
