@@ -18,8 +18,10 @@
 // ~31 us: the waves never wait for memory (vmcnt wait 8 cycles per stage; the same 57 us with every W DMA redirected to one L2-hot
 // region), they are serialised inside a stage — per stage and wave (cycle counters): DMA issue 460-750 cycles (ten instructions with
 // their m0 set-up), ds_read + split + 48 MFMAs 1 700-2 260 with nothing overlapping at one wave per SIMD, and the four waves that
-// have a SIMD to themselves wait ~850 cycles at the barrier for the fifth, which shares one.  Next: eight waves (two per SIMD,
-// 128 rows per workgroup) and the fragments of stage s + 1 read and split under the MFMAs of stage s.
+// have a SIMD to themselves wait ~850 cycles at the barrier for the fifth, which shares one.  More waves per SIMD do NOT help (tried:
+// eight waves per workgroup, one k-step per stage: 60 us; four-wave workgroups, two per CU: 62 us — ~0.9 us per k-step and wave
+// whatever shares the SIMD: a wave in its MFMA burst keeps the SIMD's issue).  What is left is inside ONE wave's instruction stream:
+// the fragments of stage s + 1 read and split in the shadows of stage s's MFMAs (~105 other instructions per 24 MFMAs today).
 #include "hp_common.h"
 #include <algorithm>
 #include <cstdlib>
@@ -32,18 +34,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kK = 2048, kSteps = kK / 32;               // MFMA k-steps of 32
-constexpr int kWaves = 4, kThreads = kWaves * 64;      // 64 rows per workgroup, TWO workgroups per CU: unsynchronised, so one's DMA
-                                                       // issue / LDS reads / split run under the other's MFMAs (8 waves of ONE workgroup
-                                                       // move in lockstep behind the per-stage barrier and want the same unit at the same time)
+constexpr int kWaves = 5, kThreads = kWaves * 64;
 constexpr int kT5Step = 12 * 1024;                       // 4 cloud tiles x 3 pieces x 1 KB per k-step
-constexpr int kG = 1, kStages = kSteps / kG;             // k-steps per pipeline stage (one barrier per stage), stages
-constexpr int kT5Ring = 3, kWRing = 4;                   // ring slots: t5 two stages ahead (L2), W three (HBM)
-constexpr int kT5Stage = kG * kT5Step;                   // 12 KB
+constexpr int kG = 2, kStages = kSteps / kG;             // k-steps per pipeline stage (one barrier per stage), stages
+constexpr int kT5Ring = 3, kWRing = 4;                   // stages in flight: t5 two ahead (L2), W three ahead (HBM)
+constexpr int kT5Stage = kG * kT5Step;                   // 24 KB
 constexpr int kWStage = kWaves * kG * 2048;              // a wave's raw fp32 fragments: two 1 KB halves per k-step
-constexpr int kLds = kT5Ring * kT5Stage + kWRing * kWStage;      // 36 + 32 = 68 KB
-constexpr int kT5Lag = (kWRing - 1) - (kT5Ring - 1);     // issue k carries W of stage k and t5 of stage k - kT5Lag
-constexpr int kT5PerWave = 3;                            // 12 fragments per stage: three per wave
-static_assert(kG == 1 && kT5PerWave * kWaves == 12, "t5 duty map");
+constexpr int kLds = kT5Ring * kT5Stage + kWRing * kWStage;      // 72 + 80 = 152 KB
 constexpr long kT5Bytes = (long)kSteps * kT5Step;        // 768 KB
 
 // x = b1 + b2 + b3 exactly (truncation): 8 values -> three fragments of 8 bf16
@@ -97,10 +94,10 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
                  : "memory");
 }
 
-// LDS: [t5 ring: 4 x 12 KB][W ring: 6 x (8 waves x 2 KB)].  A pipeline stage = one k-step; per stage a wave issues two t5 DMAs (its share
-// of the 12 fragments) and two W DMAs — issue k carries W(k) and t5(k - 2) — so at the top of stage s, which needs t5(s) (in issue
-// s + 2, in front of that issue's two W DMAs and of issues s + 3, s + 4), all but the youngest 2 + 4 + 4 operations must have landed.
-__global__ __launch_bounds__(kThreads, 2) void heads_fwd_kernel(int B, int N, const float* __restrict__ W,
+// LDS: [t5 ring: 3 x 24 KB][W ring: 4 x (5 waves x 4 KB)].  A pipeline stage = two k-steps: per stage a wave issues six t5 DMAs (its
+// share of the 24 fragments; the fifth wave repeats the first's) and four W DMAs, so at the top of stage s — which needs t5(s),
+// issued two stages ago in front of that stage's four W DMAs — all but the youngest 4 + 10 operations must have landed.
+__global__ __launch_bounds__(kThreads, 1) void heads_fwd_kernel(int B, int N, const float* __restrict__ W,
                                                                  const float* __restrict__ bias, const unsigned char* __restrict__ t5p,
                                                                  float* __restrict__ theta, int theta_ld) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[kLds];
@@ -120,36 +117,40 @@ __global__ __launch_bounds__(kThreads, 2) void heads_fwd_kernel(int B, int N, co
     const void* wbase = uniform_ptr(W);
     const void* tbase = uniform_ptr(t5p);
     const unsigned lds0 = (unsigned)(size_t)lds;
-    const int tw = w;                                                      // t5 share: fragments 3 tw .. 3 tw + 2 of a stage's 12
-    const unsigned s_t5 = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kT5PerWave * tw * 1024));
+    const int tw = w < 4 ? w : 0;                                          // t5 share: fragments 6 tw .. 6 tw + 5 of a stage's 24
+    const unsigned s_t5 = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(6 * tw * 1024));
     const unsigned s_w = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kT5Ring * kT5Stage + w * kG * 2048));
     // Workgroup g walks the contraction from stage rot(g) on, cyclically: with every workgroup at the same k all ~19 000 rows in
     // flight are read at the SAME offset of their 8 KB pitch (the same few HBM channels).
     const unsigned rot = (blockIdx.x * 5u) & (kStages - 1);
     const unsigned wrow0 = (unsigned)row_lo * (unsigned)(kK * 4) + (unsigned)(lane & 7) * 16u;
     const unsigned wrow1 = (unsigned)row_hi * (unsigned)(kK * 4) + (unsigned)(lane & 7) * 16u;
-    const unsigned trow = (unsigned)(kT5PerWave * tw * 1024 + lane * 16);
-    int nis = 0;      // issues so far.  Issue k carries W of stage k and t5 of stage k - kT5Lag; past the end the last stage is issued
-                      // again (into ring slots nobody reads any more), before the start stage 0
+    const unsigned trow = (unsigned)(6 * tw * 1024 + lane * 16);
+    int nis = 0;      // issues so far.  Issue k carries W of stage k and t5 of stage k - 1 (the 3-slot ring holds t5 two stages ahead);
+                      // past the end the last stage is issued again (into ring slots nobody reads any more)
     auto issue = [&]() {
-        const int ws = min(nis, kStages - 1), tsl = max(nis - kT5Lag, 0), ts = min(tsl, kStages - 1);
+        const int ws = min(nis, kStages - 1), ts = min(max(nis - 1, 0), kStages - 1);
         const unsigned to = trow + (((unsigned)ts + rot) & (kStages - 1)) * (unsigned)kT5Stage;
         const unsigned wk = (((unsigned)ws + rot) & (kStages - 1)) * (unsigned)(kG * 128);
-        const unsigned lt = s_t5 + (unsigned)(tsl % kT5Ring) * (unsigned)kT5Stage, lw = s_w + (unsigned)(nis % kWRing) * (unsigned)kWStage;
+        const unsigned lt = s_t5 + (unsigned)(max(nis - 1, 0) % kT5Ring) * (unsigned)kT5Stage, lw = s_w + (unsigned)(nis % kWRing) * (unsigned)kWStage;
 #pragma unroll
-        for (int i = 0; i < kT5PerWave; ++i) glds16(tbase, to + i * 1024, lt + i * 1024);
-        glds16(wbase, wrow0 + wk, lw);
-        glds16(wbase, wrow1 + wk, lw + 1024);
+        for (int i = 0; i < 6; ++i) glds16(tbase, to + i * 1024, lt + i * 1024);
+#pragma unroll
+        for (int g = 0; g < kG; ++g) {
+            glds16(wbase, wrow0 + wk + g * 128, lw + g * 2048);
+            glds16(wbase, wrow1 + wk + g * 128, lw + g * 2048 + 1024);
+        }
         ++nis;
     };
-#pragma unroll 1
-    for (int k = 0; k < kWRing - 1; ++k) issue();      // prologue: W 0..2, t5 0, 0, 1
+    issue();      // W 0, t5 0
+    issue();      // W 1, t5 0 again
+    issue();      // W 2, t5 1
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int sidx = 0; sidx < kStages; ++sidx) {
-        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");       // t5(sidx) sits in issue sidx + 1, in front of its 2 W DMAs and of issue sidx + 2
+        asm volatile("s_waitcnt vmcnt(14)" ::: "memory");      // t5(sidx) sits in issue sidx + 1, in front of its 4 W DMAs and issue sidx + 2
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         issue();      // W(sidx + 3), t5(sidx + 2): into the ring slots stage sidx - 1 just left
@@ -227,7 +228,7 @@ int hp_heads_fwd(int B, int N, const float* t5, const float* W, const float* bia
     unsigned char* t5p = reinterpret_cast<unsigned char*>(ws);
     hipLaunchKernelGGL(heads_t5_split_kernel, dim3(kSteps * 4), dim3(64), 0, stream, B, t5, t5p);
     const int ntiles = (N + 15) / 16;
-    const int grid = (ntiles + kWaves - 1) / kWaves;      // 298 workgroups for the published network: 1-2 per CU, one round
+    const int grid = (ntiles + kWaves - 1) / kWaves;      // 238 workgroups for the published network: one per CU, one round
     hipLaunchKernelGGL(heads_fwd_kernel, dim3(grid), dim3(kThreads), 0, stream, B, N, W, bias, t5p, theta, theta_ld);
     HP_RETURN_LAST_ERROR();
 }
