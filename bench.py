@@ -637,7 +637,10 @@ def main():
                                      "round 4 the hidden activations h1..h4 are STORED as such piece pairs with block exponents (22-23 "
                                      "significant bits, same bytes as fp32; error vs fp64 within 2.5x rms / 3x max of the fp32 fma chain's, "
                                      "pooled features within 2e-6: tests/test_model_gpu.py; HP_CONV_PRESPLIT=0 restores fp32 "
-                                     "activations, HP_CONV_SPLIT=0 the fp32 MFMA GEMMs)"},
+                                     "activations, HP_CONV_SPLIT=0 the fp32 MFMA GEMMs); the same split-f16 products carry the fused decoder's "
+                                     "forward, the delta chain and the dW launch of the encoders' backward (HP_EB_CHAIN16=0: fp32 MFMA), and "
+                                     "the hypernetwork heads' forward uses exact three-piece bf16 splits with six products (HP_HEADS_FWD=0: "
+                                     "fp32 GEMM) - each with its own error-vs-fp64 test against the fp32 kernel it replaces"},
             "final_loss": loss,
         }
         if not args.no_extras:
