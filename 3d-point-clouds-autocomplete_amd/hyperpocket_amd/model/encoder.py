@@ -1,65 +1,61 @@
-"""Drop-in for model/encoder.py:5-53 — same constructor, parameter names/shapes (state_dict
-compatible: conv.{0,2,4,6,8}, fc.0, mu_layer, std_layer) and return convention; the compute is
-hp_encoder_forward / hp_encoder_backward (fp32 MFMA GEMM stack + fused max-pool bookkeeping)."""
+"""PointNet-style encoder shell over hp_encoder_forward / hp_encoder_backward.
+
+Contract taken from the reference (model/encoder.py:5-53): constructor ``Encoder(config, is_vae)``, the
+state_dict key set ``conv.{0,2,4,6,8}.{weight,bias}``, ``fc.0.*``, ``mu_layer.*``, ``std_layer.*`` with
+Conv1d-shaped (Cout, Cin, 1) weights, and the return convention (VAE: ``(z, mu, exp(logvar))``; plain:
+``mu``).  Modules are created in key order so a seeded construction draws the same default-init numbers.
+This class only owns parameters; the arithmetic is one autograd node (ops.EncoderFunction).
+"""
 import torch
-import torch.nn as nn
+from torch import nn
 
 from ..ops import EncoderFunction
+
+# pointwise stack: channel widths of the 1x1 convolutions; a ReLU follows every one but the last
+POINT_WIDTHS = (3, 64, 128, 256, 512, 512)
+POOLED = POINT_WIDTHS[-1]
+
+
+def _interleave_relu(layers, after_last):
+    """[l0, relu, l1, relu, ...] — the ReLU slots carry no parameters; they exist so that the layers sit at the even
+    indices the checkpoints name."""
+    seq = []
+    for i, layer in enumerate(layers):
+        seq.append(layer)
+        if after_last or i + 1 < len(layers):
+            seq.append(nn.ReLU(inplace=True))
+    return nn.Sequential(*seq)
 
 
 class Encoder(nn.Module):
     def __init__(self, config, is_vae=False):
         super().__init__()
-
+        self.is_vae = bool(is_vae)
         self.output_size = config['output_size']
         self.use_bias = config['use_bias']
-        self.relu_slope = config['relu_slope']   # read but unused, as in the reference
-        self.is_vae = is_vae
+        self.relu_slope = config['relu_slope']       # carried, never used: the stack is plain ReLU
         if not self.use_bias:
             raise NotImplementedError("the HIP encoder path expects use_bias=true (every reference config sets it)")
 
-        # Parameter containers only (same registration order and default-init RNG consumption as the
-        # reference, so a seeded construction yields identical weights).  No BatchNorm.
-        self.conv = nn.Sequential(
-            nn.Conv1d(in_channels=3, out_channels=64, kernel_size=1, bias=self.use_bias),
-            nn.ReLU(inplace=True),
-
-            nn.Conv1d(in_channels=64, out_channels=128, kernel_size=1, bias=self.use_bias),
-            nn.ReLU(inplace=True),
-
-            nn.Conv1d(in_channels=128, out_channels=256, kernel_size=1, bias=self.use_bias),
-            nn.ReLU(inplace=True),
-
-            nn.Conv1d(in_channels=256, out_channels=512, kernel_size=1, bias=self.use_bias),
-            nn.ReLU(inplace=True),
-
-            nn.Conv1d(in_channels=512, out_channels=512, kernel_size=1, bias=self.use_bias),
-        )
-
-        self.fc = nn.Sequential(
-            nn.Linear(512, 512, bias=True),
-            nn.ReLU(inplace=True)
-        )
-
-        self.mu_layer = nn.Linear(512, self.output_size, bias=True)
-        self.std_layer = nn.Linear(512, self.output_size, bias=True)
+        pairs = zip(POINT_WIDTHS[:-1], POINT_WIDTHS[1:])
+        self.conv = _interleave_relu([nn.Conv1d(cin, cout, 1, bias=True) for cin, cout in pairs], after_last=False)
+        self.fc = _interleave_relu([nn.Linear(POOLED, POOLED)], after_last=True)
+        for head in ("mu_layer", "std_layer"):       # std_layer exists (and is saved) even when is_vae is False
+            setattr(self, head, nn.Linear(POOLED, self.output_size))
 
     def _params(self):
-        convs = [self.conv[i] for i in (0, 2, 4, 6, 8)]
-        ps = [c.weight for c in convs] + [c.bias for c in convs] + \
-             [self.fc[0].weight, self.fc[0].bias, self.mu_layer.weight, self.mu_layer.bias]
-        if self.is_vae:   # std_layer is never touched by a non-VAE encoder: its .grad stays None
-            ps += [self.std_layer.weight, self.std_layer.bias]
-        return ps
+        """Flat parameter order of the C entry points: conv weights, conv biases, fc, mu[, std]."""
+        convs = [m for m in self.conv if isinstance(m, nn.Conv1d)]
+        tail = [self.fc[0], self.mu_layer] + ([self.std_layer] if self.is_vae else [])
+        # a plain encoder never touches std_layer: its .grad stays None
+        return [c.weight for c in convs] + [c.bias for c in convs] + [t for m in tail for t in (m.weight, m.bias)]
 
     def forward(self, x, eps=None):
-        """x: (B, 3, N) as in the reference (typically the transposed *view* FullModel makes of a
-        (B, N, 3) batch — then no copy happens here), or (B, N, 3) when x.size(-1) == 3 is unambiguous
-        is NOT assumed: the reference contract is channels-first."""
-        pts = x.transpose(1, 2).contiguous()          # (B, N, 3) rows = points; free for a transposed view
-        if self.is_vae:
-            if eps is None:
-                # model/encoder.py:40 eps = torch.randn_like(std) — device RNG, plumbing
-                eps = torch.randn((pts.size(0), self.output_size), dtype=torch.float32, device=pts.device)
-            return EncoderFunction.apply(pts, eps.contiguous(), self.output_size, *self._params())
-        return EncoderFunction.apply(pts, None, self.output_size, *self._params())
+        """x is channels-first (B, 3, N) — normally the transposed view FullModel makes of a (B, N, 3) batch, for
+        which the ``contiguous()`` below is free.  ``eps`` injects the VAE draw (tests); otherwise device RNG."""
+        pts = x.transpose(1, 2).contiguous()
+        if not self.is_vae:
+            return EncoderFunction.apply(pts, None, self.output_size, *self._params())
+        if eps is None:
+            eps = torch.randn((pts.size(0), self.output_size), dtype=torch.float32, device=pts.device)
+        return EncoderFunction.apply(pts, eps.contiguous(), self.output_size, *self._params())

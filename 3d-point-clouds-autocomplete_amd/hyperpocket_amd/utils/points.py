@@ -15,33 +15,39 @@ from ..ops import sample_points
 
 
 def generate_points_from_uniform_distribution(size, low=-1, high=1):
-    while True:
-        points = torch.zeros([size[0] * 3, *size[1:]]).uniform_(low, high)
-        points = points[torch.norm(points, dim=1) < 1]
-        if points.shape[0] >= size[0]:
-            return points[:size[0]]
+    """First size[0] points of a U(low, high) box draw that fall inside the unit ball.  The draw is 3x oversized
+    (acceptance is pi/6) and repeated whole in the improbable case it comes up short — the reference's scheme
+    (utils/points.py:8-13), kept draw for draw so the torch CPU generator is consumed identically."""
+    want, rest = size[0], tuple(size[1:])
+    kept = ()
+    while len(kept) < want:
+        box = torch.zeros((3 * want,) + rest).uniform_(low, high)
+        kept = box[box.norm(dim=1) < 1]
+    return kept[:want]
 
 
 def normalization_coef(config, epoch, normalize_points=None):
-    norm = config['target_network_input']['normalization']
-    if normalize_points is None:
-        normalize_points = norm['enable']
-    if normalize_points and norm['type'] == 'progressive':
-        max_epoch = norm['epoch']
-        return float(np.linspace(0, 1, max_epoch)[epoch - 1]) if epoch <= max_epoch else 1.0
-    return 0.0
+    """Radius c of the progressive hollow: linspace(0, 1, E)[epoch-1] up to epoch E, then 1; 0 when disabled."""
+    rule = config['target_network_input']['normalization']
+    enabled = rule['enable'] if normalize_points is None else normalize_points
+    if not (enabled and rule['type'] == 'progressive'):
+        return 0.0
+    last = rule['epoch']
+    return float(np.linspace(0, 1, last)[epoch - 1]) if epoch <= last else 1.0
 
 
 def generate_points(config, epoch, size, normalize_points=None):
-    coef = normalization_coef(config, epoch, normalize_points)
-    points = generate_points_from_uniform_distribution(size=size)
-    if coef > 0.0:
-        norms = np.linalg.norm(points, axis=1)
-        sel = norms < coef
-        if sel.any():
-            sub = points[sel]
-            points[sel] = coef * (sub.T / torch.from_numpy(np.linalg.norm(sub, axis=1)).float()).T
-    return points
+    """utils/points.py:16-36: ball points, those nearer the origin than c pushed out onto the sphere of radius c
+    (norms through numpy on the fp32 values, as the reference takes them)."""
+    c = normalization_coef(config, epoch, normalize_points)
+    pts = generate_points_from_uniform_distribution(size=size)
+    if c > 0.0:
+        inner = np.linalg.norm(pts, axis=1) < c
+        if inner.any():
+            moved = pts[inner]
+            radius = torch.from_numpy(np.linalg.norm(moved, axis=1)).float()
+            pts[inner] = c * (moved.T / radius).T
+    return pts
 
 
 def sample_points_device(config, epoch, batch, n, device, seed, offset):

@@ -9,12 +9,11 @@ The materialising functions stay available in StructuralLossesBackend.
 import ctypes
 
 import torch
-from torch.autograd import Function
 
 from ..._lib import call, check_input, current_stream, load_library
 
 
-class MatchCostFunction(Function):
+class MatchCostFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, seta, setb):
         seta, setb = seta.contiguous(), setb.contiguous()
@@ -38,10 +37,8 @@ class MatchCostFunction(Function):
 
     @staticmethod
     def backward(ctx, grad_output):
-        grad_output_expand = grad_output.unsqueeze(1).unsqueeze(2)
-        grada = ctx.grada * grad_output_expand if ctx.grada is not None else None
-        gradb = ctx.gradb * grad_output_expand if ctx.gradb is not None else None
-        return grada, gradb
+        per_cloud = grad_output.reshape(-1, 1, 1)        # d(loss)/d(cost_b), broadcast over that cloud's points
+        return tuple(None if g is None else g * per_cloud for g in (ctx.grada, ctx.gradb))
 
 
 match_cost = MatchCostFunction.apply
