@@ -3,6 +3,7 @@
 Each Function's forward/backward is ONE call into libhyperpocket_hip.so (which issues the whole
 launch sequence on the current stream); PyTorch only owns the memory and the autograd wiring.
 """
+import contextlib
 import ctypes
 from ctypes import c_int, c_long, c_void_p
 
@@ -51,6 +52,31 @@ def _long_fn(name, *args):
     fn = getattr(load_library(), name)
     fn.restype = c_long
     return fn(*args)
+
+
+# ---------------------------------------------------------------------------------------------
+# Arithmetic: by default the wide GEMM-shaped kernels form each fp32 product on the f16 / bf16 matrix pipe from
+# exact pieces of the fp32 operands (fp32 accumulation; see bench.py config.arithmetic).  Every one of them has an
+# IEEE-fp32 form (v_mfma_f32_* / VALU fma) behind a process-wide switch of the library.
+# ---------------------------------------------------------------------------------------------
+_PIECE_SWITCHES = ("hp_conv_split_set",                   # encoder conv stack: two f16 pieces per operand
+                   "hp_conv_presplit_set",                # ... hidden activations stored as piece pairs
+                   "hp_encoder_backward_set_chain_f16",   # encoder backward: delta chain + dW launch
+                   "hp_hypernet_set_heads_stream",        # hypernetwork heads' forward: three bf16 pieces
+                   "hp_target_fused_set_f16")             # fused decoder forward
+
+
+@contextlib.contextmanager
+def strict_fp32():
+    """Inside the block every kernel computes its products in fp32 (no f16 / bf16 pieces): the arithmetic the
+    reference states.  The switches are process-wide (not per stream or thread) and restored on exit."""
+    lib = load_library()
+    was = [getattr(lib, name)(0) for name in _PIECE_SWITCHES]
+    try:
+        yield
+    finally:
+        for name, prev in zip(_PIECE_SWITCHES, was):
+            getattr(lib, name)(prev)
 
 
 # ---------------------------------------------------------------------------------------------

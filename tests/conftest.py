@@ -31,6 +31,26 @@ def golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
 
 
+def fixture_state_(tensors, g):
+    """Bring seeded-init parameters to the state a model fixture was captured at.  `tensors`: name -> tensor under the
+    reference's state_dict names (a module's state_dict() or the oracle's parameter dict), modified in place.  Plain
+    fixtures are captured at the seeded init: nothing to do.  model_trained.npz (tests/golden/make_golden.py,
+    train_to_operating_point) carries a recipe: the hypernetwork heads' weights times 2**head_scale_log2 (exact), then
+    the trained values of the small tensors the reference's train_epoch updated."""
+    if "head_scale_log2" not in g:
+        return tensors
+    import torch
+    scale = 2.0 ** int(g["head_scale_log2"])
+    with torch.no_grad():
+        for k, t in tensors.items():
+            if k.startswith("hyper_network.output.") and k.endswith(".weight"):
+                t.mul_(scale)
+            key = "trained__" + k.replace(".", "__")
+            if key in g:
+                t.copy_(torch.from_numpy(g[key]).to(t.dtype))
+    return tensors
+
+
 class OracleLib:
     """ctypes view of oracle/libstructural_losses_ref.so (the C restatement)."""
 

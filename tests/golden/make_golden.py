@@ -17,6 +17,9 @@ What is pinned (reference file:line)
                                  vectors, loss, parameter-gradient statistics)
   train_steps                  : core/epoch_loops.py:8-46 driven for 3 steps with Adam
                                  (core/main.py:62-66 hyper-parameters)
+  model_trained                : the same capture as model_small at a partially TRAINED state reached
+                                 by 400 steps of the reference's train_epoch (recipe at
+                                 train_to_operating_point below)
 `weights_init` / `seed_setup` (core/setup.py:12-19,63-77) cannot be imported (circular
 import through utils.util -> datasets) and are restated below.
 """
@@ -128,6 +131,27 @@ class Recorder:
         torch.randn_like = self._rl
 
 
+class ReluMargins:
+    """Smallest |pre-activation| over the 2-D ReLU inputs of a forward (decoder layers (N, C), hypernetwork trunk and
+    encoder fc (B, C)); the encoders' conv ReLUs (3-D inputs) are not watched — their gradients only flow through the
+    max-pool's critical points and are compared through the fp64 oracle when they disagree (tests)."""
+
+    def __enter__(self):
+        self.closest = float("inf")
+        self._fwd = torch.nn.ReLU.forward
+        me = self
+
+        def fwd(mod, x):
+            if x.dim() == 2:
+                me.closest = min(me.closest, float(x.detach().abs().min()))
+            return me._fwd(mod, x)
+        torch.nn.ReLU.forward = fwd
+        return self
+
+    def __exit__(self, *a):
+        torch.nn.ReLU.forward = self._fwd
+
+
 def param_stats(model, rng_idx):
     stats = {}
     for name, p in model.named_parameters():
@@ -153,7 +177,50 @@ def weight_checksums(model):
             for n, p in model.named_parameters()}
 
 
-def model_fixture(name, random_out, real_out, b, n_exist, n_gt, seed, epoch):
+# ---- the partially trained operating point (model_trained.npz) ---------------------------------------------------------
+# A state_dict is 173 MB, so a trained one cannot be a fixture.  What travels instead is a RECIPE both sides can replay
+# exactly plus the trained values of the small tensors:
+#   1. seeded construction + weights_init (as every other fixture);
+#   2. the hypernetwork heads' weight matrices multiplied by 2**-6 (exact in fp32) and, like the other wide matrices
+#      (trunk layers 4-5, conv layers 3-5, fc / mu / std weights), left untouched from then on;
+#   3. the reference's own train_epoch (core/epoch_loops.py:8-46) with torch.optim.Adam(lr 1e-4) over the remaining
+#      134 147 values (every bias, trunk layers 1-3, conv layers 1-2) for TRAINED_STEPS steps on the fixture's fixed batch.
+# rec then sits at gt's scale (std ~0.27 against 0.29, Chamfer term ~2 against 4e6 at init) — the regime training visits,
+# where EMD costs carry mass and arg-mins are spread — and the fixture stores those 134 147 trained values.
+TRAINED_HEAD_SCALE_LOG2 = -6
+TRAINED_STEPS = 400
+
+
+def trained_subset(model):
+    """Names of the parameters step 3 trains (state_dict keys)."""
+    frozen = ("hyper_network.output.", "hyper_network.model.6.weight", "hyper_network.model.8.weight",
+              "conv.4.weight", "conv.6.weight", "conv.8.weight", "fc.0.weight", "mu_layer.weight", "std_layer.weight")
+    return [k for k, _ in model.named_parameters()
+            if k.endswith(".bias") or not any(f in k for f in frozen)]
+
+
+def train_to_operating_point(model, batch, epoch):
+    existing, missing, gt = batch
+    with torch.no_grad():
+        for head in model.hyper_network.output:
+            head.weight.mul_(2.0 ** TRAINED_HEAD_SCALE_LOG2)
+    names = trained_subset(model)
+    params = dict(model.named_parameters())
+    opt = torch.optim.Adam([params[k] for k in names], lr=1e-4, weight_decay=0, betas=(0.9, 0.999), amsgrad=False)
+    for s in range(TRAINED_STEPS):
+        loader = [(existing.clone(), missing.clone(), gt.clone(), 0)]
+        _, _, loss_all, loss_kld, loss_r, _, _, _ = train_epoch(epoch, model, opt, loader, torch.device("cpu"),
+                                                                ChamferLoss(), 0.05)
+        if s % 50 == 0 or s == TRAINED_STEPS - 1:
+            print(f"  trained-fixture step {s}: loss_all {float(loss_all) / 2:.4f} loss_r {float(loss_r) / 2:.4f}", flush=True)
+    model.zero_grad(set_to_none=True)     # the frozen tensors accumulated gradients nobody cleared
+    extra = {"trained__" + k.replace(".", "__"): f32(params[k]) for k in names}
+    extra["head_scale_log2"] = np.array(TRAINED_HEAD_SCALE_LOG2)
+    extra["trained_steps"] = np.array(TRAINED_STEPS)
+    return extra
+
+
+def model_fixture(name, random_out, real_out, b, n_exist, n_gt, seed, epoch, prepare=None, margin=None):
     cfg = model_config(random_out, real_out)
     torch.manual_seed(seed)
     model = FullModel(copy.deepcopy(cfg))
@@ -167,14 +234,35 @@ def model_fixture(name, random_out, real_out, b, n_exist, n_gt, seed, epoch):
     else:
         missing = torch.zeros(b)  # Completion3D collates int 0 (datasets/shapenet_completion3d.py:41-48)
         gt = torch.rand(b, n_gt, 3, generator=g) - 0.5
-    ex_in, mi_in = existing.clone(), missing.clone()
-    gt_shape = list(gt.shape)
-    torch.manual_seed(seed + 2)
-    with Recorder() as rec:
-        out = model(ex_in, mi_in, gt_shape, epoch, torch.device("cpu"))
+    extra = prepare(model, (existing, missing, gt), epoch) if prepare else {}
+    # `margin`: pick the random draws (decoder points, VAE eps) of the captured step so that every DISCRETE decision on
+    # the gradient's path has room: no ReLU pre-activation of the decoder / hypernetwork trunk / encoder tails within
+    # `margin` of zero, no Chamfer arg-min whose runner-up is within `margin`.  At a trained state the parameter gradients
+    # are small residuals of large cancelling per-point terms, and ONE flipped ReLU mask (a pre-activation of 1e-8 rounding
+    # to either side of zero) moves entries of the hypernetwork's gradient by 1e-3 of the tensor's scale — in the
+    # reference's own fp32 arithmetic as much as in any other.  With the margin, every implementation that is accurate to
+    # fp32 rounding must reproduce the captured gradients; the draw index is stored.
+    draw = 0
+    while True:
+        ex_in, mi_in = existing.clone(), missing.clone()
+        gt_shape = list(gt.shape)
+        torch.manual_seed(seed + 2 + draw)
+        with Recorder() as rec, ReluMargins() as relu:
+            out = model(ex_in, mi_in, gt_shape, epoch, torch.device("cpu"))
+        if margin is None:
+            break
+        P = ChamferLoss().batch_pairwise_dist(gt, out[0].detach().permute(0, 2, 1))
+        gaps = [float((t[..., 1] - t[..., 0]).min()) for t in (torch.topk(P, 2, dim=1, largest=False)[0].transpose(1, 2),
+                                                                torch.topk(P, 2, dim=2, largest=False)[0])]
+        if relu.closest >= margin and min(gaps) >= margin:
+            print(f"  draw {draw}: closest ReLU pre-activation {relu.closest:.2e}, smallest arg-min gap {min(gaps):.2e}")
+            extra["draw"] = np.array(draw)
+            break
+        draw += 1
+        assert draw < 2000, "no draw with the requested margins"
     reconstruction, logvar, mu = out
     loss_r = torch.mean(0.05 * ChamferLoss()(gt, reconstruction.permute(0, 2, 1)))
-    data = dict(existing=f32(existing), gt=f32(gt), rec=f32(reconstruction),
+    data = dict(existing=f32(existing), gt=f32(gt), rec=f32(reconstruction), **extra,
                 points=np.stack([f32(p) for p in rec.points]),
                 loss_r=f32(loss_r), seed=np.array(seed), epoch=np.array(epoch),
                 random_out=np.array(random_out), real_out=np.array(real_out))
@@ -256,12 +344,17 @@ def train_steps_fixture():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    only = sys.argv[1:]          # e.g. `make_golden.py model_trained`: regenerate that fixture alone
+    if only == ["model_trained"]:
+        model_fixture("model_trained", 128, 128, 4, 128, 256, 4242, 120, prepare=train_to_operating_point, margin=2e-6)
+        sys.exit(0)
     chamfer_fixtures()
     points_fixtures()
     model_fixture("model_small", 128, 128, 2, 96, 192, 1856, 1)      # HyperPocket
     model_fixture("model_small_e60", 128, 128, 3, 50, 120, 77, 60)   # HyperPocket, ragged sizes, epoch 60
     model_fixture("model_hyperrec", 0, 128, 2, 160, 160, 2020, 120)  # HyperRec (Completion3D config)
     model_fixture("model_hypercloud", 128, 0, 2, 96, 96, 31, 10)     # HyperCloud
+    model_fixture("model_trained", 128, 128, 4, 128, 256, 4242, 120, prepare=train_to_operating_point, margin=2e-6)
     train_steps_fixture()
     meta = {"torch": torch.__version__, "numpy": np.__version__, "reference": REF}
     json.dump(meta, open(os.path.join(OUT, "META.json"), "w"), indent=1)

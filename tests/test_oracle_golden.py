@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden
+from conftest import fixture_state_, golden
 
 
 # ----------------------------------------------------------------------------- NN distance / Chamfer
@@ -61,13 +61,17 @@ def test_generate_points_oracle_bit_exact(ref):
 
 
 # ----------------------------------------------------------------------------- model forward / backward
+# model_trained: the same capture at a partially trained state (rec at gt's scale), see conftest.fixture_state_
+MODEL_FIXTURES = ["model_small", "model_small_e60", "model_hyperrec", "model_hypercloud", "model_trained"]
+
+
 def _load_case(ref, name):
     g = golden(name)
-    P = ref.init_params(int(g["seed"]), int(g["random_out"]), int(g["real_out"]))
+    P = fixture_state_(ref.init_params(int(g["seed"]), int(g["random_out"]), int(g["real_out"])), g)
     return g, P
 
 
-@pytest.mark.parametrize("name", ["model_small", "model_small_e60", "model_hyperrec", "model_hypercloud"])
+@pytest.mark.parametrize("name", MODEL_FIXTURES)
 def test_init_params_reproduces_reference_weights(ref, name):
     g, P = _load_case(ref, name)
     for k, v in P.items():
@@ -76,7 +80,7 @@ def test_init_params_reproduces_reference_weights(ref, name):
         assert abs(v.double().norm().item() - s[1]) <= 1e-9 * s[1] + 1e-12, k
 
 
-@pytest.mark.parametrize("name", ["model_small", "model_small_e60", "model_hyperrec", "model_hypercloud"])
+@pytest.mark.parametrize("name", MODEL_FIXTURES)
 def test_model_oracle_matches_reference(ref, name):
     g, P = _load_case(ref, name)
     existing = torch.from_numpy(g["existing"])
