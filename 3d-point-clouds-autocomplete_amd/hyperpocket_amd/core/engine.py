@@ -114,6 +114,7 @@ class FusedHeadsAdam:
         self.stream = torch.cuda.Stream(device=engine.flat.flat.device) if own_stream else None
         self._keep = self._job = None
         self.ran = False           # the pass of the step in flight has been launched (step() then leaves the heads to it)
+        self.broken = None         # set by abort(): why the heads are out of step with the rest of the model
         import os
         self.defer = os.environ.get("HP_HEADS_ADAM_DEFER", "1") != "0"
         # Round 4: the pass starts right behind the heads' dX inside the hypernetwork's backward (hp_hypernet_backward_ordered
@@ -192,11 +193,27 @@ class FusedHeadsAdam:
     def abort(self):
         """The step in flight failed: a pass that was handed over but not launched is DROPPED (launching it would move
         weights and moments of a step that is not counted; a retry would apply the update twice with one bias-correction
-        step number), a pass already running on the side stream is waited for."""
+        step number), a pass already running on the side stream is waited for.  With `early` the pass starts inside the
+        hypernetwork's backward, i.e. BEFORE the trunk's and the encoders' backward: when those fail, the heads' weights
+        and moments have already taken the update of a step nothing else took.  That cannot be undone here (the update is
+        in place and the gradient was never stored), so it is recorded: the owner refuses further steps until a
+        checkpoint is loaded."""
         self._job = None
         if self.stream is not None and self._keep is not None:
             torch.cuda.current_stream(self.flat.flat.device).wait_stream(self.stream)
         self._keep = None
+        if self.ran:
+            self.broken = ("the fused dW + Adam pass of the hypernetwork heads had already run (in place) when backward() "
+                           "failed: the heads' weights and Adam moments are one update ahead of every other parameter.  "
+                           "Reload model and optimiser state from a checkpoint (load_state_dict + load_optimizer_state_dict), "
+                           "or build the engine with fuse_heads_adam=False if backward() is expected to fail.")
+
+    def check(self):
+        if self.broken:
+            raise RuntimeError("engine state inconsistent: " + self.broken)
+        if self.ran or self._job is not None:
+            raise RuntimeError("engine state inconsistent: a fused heads update from a previous backward() was never "
+                               "consumed by a step (did backward() raise?).  Reload a checkpoint.")
 
 
 class TrainEngine:
@@ -293,7 +310,7 @@ class TrainEngine:
         model.hyper_network._heads_exchange = exch
         model._after_encoder_tails = self.fused if (self.fused is not None and self.fused.stream is not None) else None
         if self.fused is not None:
-            self.fused.ran = False
+            self.fused.check()     # (a pass left over from a failed step must not be cleared silently)
         # forward() transposes its inputs in place: hand it views it may mutate
         rec, logvar, mu = model(existing.view(existing.shape), None if missing is None else missing.view(missing.shape),
                                 list(gt.shape), epoch, device, points=points, eps=eps_noise)
@@ -330,6 +347,8 @@ class TrainEngine:
             # into the hypernetwork backward)
             # (the heads are skipped only if their fused pass really ran for this step)
             self._adam_range(self.fused.hi if (self.fused is not None and self.fused.ran) else 0, self.flat.total)
+            if self.fused is not None:
+                self.fused.ran = False          # consumed: this step is counted for the heads and for everything else
             # The heads' pass (936 MB of HBM traffic whatever the batch: ~180 us) is joined where its result is next READ —
             # `finish_pending`, right before the next step's hypernetwork forward — not here: at B = 64 it ends inside the
             # encoders' backward anyway, at B = 32 the compute stream would otherwise idle ~130 us for it at the step end
@@ -518,6 +537,8 @@ class TrainEngine:
             vv[i].copy_(st["exp_avg_sq"].to(vv[i].device).view_as(vv[i]))
             steps = max(steps, int(float(st["step"])))
         self.steps = self._adam_step = steps
+        if self.fused is not None:       # a restored checkpoint is a consistent state again
+            self.fused.broken, self.fused.ran, self.fused._job = None, False, None
 
     def _install_overlap_hook(self):
         # fires when autograd has finished the HyperNetFunction node, i.e. when the gradient w.r.t. the latent exists

@@ -72,7 +72,9 @@ class FlatAdam(torch.optim.Optimizer):
             raise RuntimeError(
                 "FlatAdam.zero_grad(): the previous backward() already applied (or queued) the fused Adam update of the "
                 "hypernetwork heads, but step() was not called for it — the rest of the model would miss that step.  Call "
-                "step() after every backward(), or build FlatAdam(model, ..., fuse_heads=False).")
+                "step() after every backward(), or build FlatAdam(model, ..., fuse_heads=False).  (If that backward() "
+                "raised part-way, the heads are one update ahead of the other parameters: reload model and optimiser "
+                "state from a checkpoint; load_state_dict() on this optimiser clears the condition.)")
         self.flat.clear_param_grads()
 
     @torch.no_grad()
@@ -141,3 +143,6 @@ class FlatAdam(torch.optim.Optimizer):
             vv[i].copy_(st["exp_avg_sq"].to(vv[i].device).view_as(vv[i]))
             steps = max(steps, int(float(st["step"])))
         self.steps, self._adam_step = steps, steps + 1
+        if self.fused is not None:       # a restored checkpoint is a consistent state again
+            self.fused.abort()
+            self.fused.broken, self.fused.ran = None, False

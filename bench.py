@@ -15,10 +15,15 @@ B=64 clouds per GPU, existing/missing (B,1024,3), gt (B,2048,3), fp32 ("Chamfer+
 value = clouds/s over all ranks (weak scaling: B per GPU fixed).
 
 One JSON line on rank 0; besides the contract keys it carries
-  roofline      the widest matrix kernel (conv5 + max-pool of the encoder stack: f16 pipe, both operands stored as f16 piece pairs), timed live with HIP events
-  roofline_emd  the EMD sweep family (45 % of the step): VALU issue cycles of the compiled loops / measured time
-  cpu_baseline  the oracle's torch-CPU restatement of the reference step timed on this box's cores
-  breakdown     extra figures (Chamfer-only step, per-op times) — informational
+  roofline        the DOMINANT kernel family of the step — the EMD sweeps (emd_rows1 / emd_rows2 / emd_grad2: about half of the
+                  step's kernel time), bound by the quarter-rate v_exp_f32: achieved = the algorithm's 27 exponentials per point
+                  pair / the call's duration measured live with HIP events, peak = the chip's exponential rate
+  roofline_mfma   the widest matrix kernel (conv5 + max-pool of the encoder stack: f16 pipe, both operands stored as f16
+                  piece pairs), timed live with HIP events against the f16 matrix peak / 3 products
+  reference_loop  the same model driven the way the reference's untouched core/epoch_loops.py drives it (Chamfer-only loss,
+                  pinned host inputs, 3 x .item(), the caller's optimiser): clouds/s, and how the gap to the engine splits
+  cpu_baseline    the oracle's torch-CPU restatement of the reference step timed on this box's cores (16 threads and all)
+  breakdown       extra figures (Chamfer-only step, the step with every kernel on its IEEE-fp32 form, one-rank RCCL) — informational
 """
 import argparse
 import copy
@@ -56,6 +61,8 @@ PEAK_F16_MFMA_TFLOPS = 2516.6    # MI355X_MICROARCH.md: dense f16/bf16 matrix pe
 PEAK_F32_VALU_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector peak (64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak
 PEAK_VALU_ISSUE_TCYC = 1024 * 2.4e9 / 1e12   # SIMD issue cycles per second: 256 CUs x 4 SIMDs x 2.4 GHz (same guide)
+EXP_ISSUE_CYCLES = 8.0                       # v_exp_f32: quarter-rate transcendental, 8 issue cycles per 64-lane wave-instruction
+PEAK_TEXP_PER_S = PEAK_VALU_ISSUE_TCYC / EXP_ISSUE_CYCLES * 64.0   # 19.66 T exponentials/s if the chip issued nothing else
 
 
 def synth_batch(b, n_half, device, seed):
@@ -96,8 +103,9 @@ def event_time_ms(fn, iters, warm=2):
     return s.elapsed_time(e) / iters
 
 
-def roofline_dominant_kernel(batch, n_half, minimal=False):
-    """The widest matrix kernel of the step: layer 5 of the encoders' conv stack with its fused max-pool,
+def roofline_widest_matrix_kernel(batch, n_half, minimal=False):
+    """The widest MATRIX kernel of the step (5 % of its kernel time; the dominant family is the EMD sweeps, roofline_emd):
+    layer 5 of the encoders' conv stack with its fused max-pool,
     max over points of A(M x 512) W(512 x 512)^T + b, M = B*1024 points of one encoder (the step batches both encoders into one
     launch of twice the tiles: `paired_launch` times that shape too).  Round 3 moved the layer from the fp32 matrix pipe
     (gemm_kernel<128,128,4,2,16,4>, v_mfma_f32_32x32x2_f32, 0.79 of 157.3 TFLOP/s) to the f16 pipe with every fp32 operand as two
@@ -168,11 +176,16 @@ def cpu_baseline(n_half, emd_coef, sample_b=4, timed_steps=2, full_b=64):
     the same per-cloud shape and loss terms, 1 warm-up + `timed_steps` timed steps — the headline `value` — and, when the
     host is fast enough for it to stay within ~60 s, one warm-up + one timed step at the metric's own batch `full_b`."""
     from oracle import hyperpocket_ref as ref
-    # torch's CPU kernels stop scaling (and thrash across NUMA domains) far below a 256-core host: 16 threads
+    # torch's CPU kernels stop scaling (and thrash across NUMA domains) far below a 256-core host: the headline leg runs on 16
+    # threads; the same sample is timed once more on every core the host has (SURVEY 8d asked for os.cpu_count()) and reported
+    # beside it
     host_cores = os.cpu_count() or 1
     threads = min(16, host_cores)
-    torch.set_num_threads(threads)
-    os.environ["OMP_NUM_THREADS"] = str(threads)      # the C EMD oracle parallelises over clouds
+
+    def use(n_threads):
+        torch.set_num_threads(n_threads)
+        os.environ["OMP_NUM_THREADS"] = str(n_threads)      # the C EMD oracle parallelises over clouds
+    use(threads)
 
     def leg(b, steps):
         P = ref.init_params(2020)
@@ -206,6 +219,26 @@ def cpu_baseline(n_half, emd_coef, sample_b=4, timed_steps=2, full_b=64):
     elif full_b and full_b != sample_b:
         out["at_metric_batch"] = {"value": None, "batch": full_b,
                                   "sample": f"skipped: ~{est:.0f} s estimated from the B={sample_b} leg (bound: 60 s)"}
+    if host_cores > threads:
+        # more threads: 64 first; every core only if that was not already slower (at 256 threads one B=4 step took 73 s on the
+        # round-5 box — torch's CPU kernels and OpenMP thrash across the NUMA domains — recorded in profiles/r05_cpu_baseline_threads.json;
+        # the default run must stay within minutes)
+        out["more_threads"] = []
+        best = dt
+        for n_thr in sorted({min(64, host_cores), host_cores}):
+            if n_thr <= threads:
+                continue
+            if out["more_threads"] and out["more_threads"][-1]["s_per_step"] > 1.5 * best and not os.environ.get("HP_BENCH_ALL_CORES"):
+                out["more_threads"].append({"cores": n_thr, "value": None,
+                                            "sample": "skipped: the previous leg was already >1.5x slower than 16 threads "
+                                                      "(HP_BENCH_ALL_CORES=1 forces it)"})
+                continue
+            use(n_thr)
+            dt_n = leg(sample_b, 1)
+            out["more_threads"].append({"cores": n_thr, "value": round(sample_b / dt_n, 3), "unit": "clouds/s", "s_per_step": round(dt_n, 2),
+                                        "sample": f"1 timed step (after 1 warm-up) at B={sample_b} with {n_thr} threads"})
+            best = min(best, dt_n)
+        use(threads)
     return out
 
 
@@ -374,14 +407,19 @@ def _pmc_profile(suffix):
 
 
 def roofline_emd(batch, n):
-    """The EMD sweep family (emd_rows1/rows2/grad2: the largest time block of the Chamfer+EMD step) against its own bound.
-    It is neither HBM- nor MFMA-bound (scalar-path candidates, 440-810 GB/s, no matrix work): it is bound by VALU ISSUE —
-    each (row, candidate-pair) costs a fixed instruction sequence, quarter-rate v_exp_f32 included.  Model: per kernel,
-    the VALU instructions of the compiled inner loop priced at MI355X_MICROARCH.md's issue costs (transcendental 8,
-    every other vector op 4 cycles per wave-instruction) x the wave-instructions one hp_emd_forward call executes
-    (profiles/rNN_emd_issue_model.json of the latest round, produced by tools/emd_issue_model.py from the shipped code object's ISA).
-    achieved = those useful issue cycles / the call's duration measured live with HIP events; peak = issue cycles the
-    chip has (1024 SIMDs x 2.4 GHz)."""
+    """The DOMINANT kernel family of the Chamfer+EMD step: the EMD sweeps of one hp_emd_forward call (emd_rows1 x9, emd_rows2 x9,
+    emd_grad2 — 47 % of the step's kernel time in profiles/).  Neither HBM- nor MFMA-bound: the match-free design
+    removed the 20.4 GB/call of `match` traffic SURVEY 8(d) prices (measured: ~1 GB/call), and there is no matrix work; what
+    bounds it is the quarter-rate v_exp_f32.  SURVEY 8(d) fixes the ALGORITHMIC work at 27 exponentials per point pair (three
+    phases x nine levels, approxmatch.cu:86,131,185), so
+        achieved = 27 * B * n * m exponentials / the call's duration (HIP events, measured live here)
+        peak     = 1024 SIMDs x 2.4 GHz / 8 issue cycles per v_exp_f32 wave-instruction x 64 lanes = 19.66 T exp/s
+        frac     = achieved / peak      (the floor VERDICT r4 recomputed: 369 us at B=64, n=2048)
+    Sub-fields: `executed` prices the 36 exponentials per pair the call really executes (the match-free cost / gradient sweep
+    re-evaluates the nine of the final match); `issue_stream` is the builder's finer model — every VALU instruction of the
+    compiled inner loops at the guide's issue cost (profiles/rNN_emd_issue_model.json, tools/emd_issue_model.py) / the same
+    duration: how close the launches are to what THEIR instruction streams allow, not a roofline fraction.
+    `traffic`: HBM bytes per call from the PMC passes under profiles/."""
     from hyperpocket_amd._lib import call, current_stream, load_library
     import ctypes
     model_name, model = _pmc_profile("emd_issue_model.json")
@@ -398,25 +436,28 @@ def roofline_emd(batch, n):
     g2 = torch.empty((batch, n, 3), **f32)
     st = current_stream(a.device)
     ms = event_time_ms(lambda: call("hp_emd_forward", batch, n, n, a, c, temp, ws, part, cost, None, g2, st), iters=20, warm=10)
-    out = {"bound": "valu-issue", "kernel": "hp_emd_forward = emd_rows1_kernel x9 + emd_rows2_kernel x9 + emd_grad2_kernel "
-           f"(B={batch}, n=m={n}, grad2 + cost)", "avg_call_ms": round(ms, 4), "peak": round(PEAK_VALU_ISSUE_TCYC, 4),
-           "unit": "T issue-cycles/s", "exp_per_call": 36.0 * batch * n * n}
-    # the ALGORITHMIC floor next to the issue-stream form: SURVEY 8(d) fixes 27 exponentials per point pair
-    # (approxmatch.cu:86,131,185: three phases x nine levels); v_exp_f32 is quarter-rate = 8 issue cycles per 64-lane
-    # wave-instruction.  The call executes 36 (the match-free path re-evaluates the nine of the last sweep).
-    alg_cyc = 27.0 * batch * n * n / 64.0 * 8.0
-    out["algorithmic"] = {"exp_per_pair": 27, "issue_cycles_per_call": alg_cyc,
-                          "frac": round(alg_cyc / (ms * 1e-3) / 1e12 / PEAK_VALU_ISSUE_TCYC, 4),
-                          "frac_of_executed_exp": round(36.0 / 27.0 * alg_cyc / (ms * 1e-3) / 1e12 / PEAK_VALU_ISSUE_TCYC, 4),
-                          "what": "exponentials alone (27 per pair, 8 issue cycles per wave-instruction) / time / (1024 SIMDs x 2.4 GHz); "
-                                  "frac_of_executed_exp prices the 36 per pair the match-free call executes"}
+    pairs = float(batch) * n * n
+    achieved = 27.0 * pairs / (ms * 1e-3) / 1e12
+    out = {"bound": "valu-exp",
+           "kernel": "hp_emd_forward = emd_rows1_kernel x9 + emd_rows2_kernel x9 + emd_grad2_kernel "
+                     f"(B={batch}, n=m={n}, cost + d cost/d xyz2; inputs U(-0.5,0.5)^3 — the launches' duration does not depend on the data)",
+           "achieved": round(achieved, 3), "peak": round(PEAK_TEXP_PER_S, 2), "unit": "Texp/s",
+           "frac": round(achieved / PEAK_TEXP_PER_S, 4),
+           "avg_call_ms": round(ms, 4), "exp_per_pair": 27, "exp_per_call": 27.0 * pairs,
+           "floor_ms": round(27.0 * pairs / PEAK_TEXP_PER_S / 1e12 * 1e3, 4),
+           "peak_is": "1024 SIMDs x 2.4 GHz / 8 issue cycles per v_exp_f32 wave-instruction x 64 lanes (MI355X_MICROARCH.md issue costs)",
+           "executed": {"exp_per_pair": 36, "frac": round(36.0 / 27.0 * achieved / PEAK_TEXP_PER_S, 4),
+                        "what": "the match-free call evaluates 27 + 9 exponentials per pair (the final sweep rebuilds the match entries)"}}
     if model and model.get("batch") == batch and model.get("n") == n:
         cyc = model["issue_cycles_per_call"]
-        out.update({"achieved": round(cyc / (ms * 1e-3) / 1e12, 4), "frac": round(cyc / (ms * 1e-3) / 1e12 / PEAK_VALU_ISSUE_TCYC, 4),
-                    "issue_cycles_per_call": cyc, "model": f"profiles/{model_name}",
-                    "traffic": model.get("hbm_bytes_per_call")})
+        out["issue_stream"] = {"frac": round(cyc / (ms * 1e-3) / 1e12 / PEAK_VALU_ISSUE_TCYC, 4), "issue_cycles_per_call": cyc,
+                               "peak_T_issue_cycles_per_s": round(PEAK_VALU_ISSUE_TCYC, 4), "model": f"profiles/{model_name}",
+                               "what": "all VALU instructions of the compiled sweep loops at their issue cost / time / (1024 SIMDs x 2.4 GHz): "
+                                       "a model of the instruction stream, not the algorithmic roofline"}
+        out["traffic"] = model.get("hbm_bytes_per_call")
+        out["traffic_source"] = f"profiles/{model_name} (rocprofv3 --pmc passes; not measured in this run)"
     else:
-        out.update({"achieved": None, "frac": None, "traffic": None})
+        out["traffic"] = None
     return out
 
 
@@ -524,11 +565,12 @@ def main():
         rendezvous_only(args, int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")))
         return
     if args.roofline_minimal:
-        print(json.dumps({"roofline": roofline_dominant_kernel(args.batch, args.points // 2, minimal=True)}), flush=True)
+        print(json.dumps({"roofline": roofline_widest_matrix_kernel(args.batch, args.points // 2, minimal=True)}), flush=True)
         return
     if args.roofline_only:
         torch.cuda.set_device(0)
-        print(json.dumps({"roofline": roofline_dominant_kernel(args.batch, args.points // 2)}), flush=True)
+        print(json.dumps({"roofline": roofline_emd(args.batch, args.points),
+                          "roofline_mfma": roofline_widest_matrix_kernel(args.batch, args.points // 2)}), flush=True)
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -644,9 +686,11 @@ def main():
             "final_loss": loss,
         }
         if not args.no_extras:
-            line["roofline"] = roofline_dominant_kernel(args.batch, n_half)
             if emd_coef:
-                line["roofline_emd"] = roofline_emd(args.batch, args.points)
+                line["roofline"] = roofline_emd(args.batch, args.points)
+                line["roofline_mfma"] = roofline_widest_matrix_kernel(args.batch, n_half)
+            else:       # Chamfer-only step: no EMD launches; the widest matrix kernel is the roofline object
+                line["roofline"] = roofline_widest_matrix_kernel(args.batch, n_half)
             if world == 1:
                 # informational: the reference-faithful Chamfer-only step on the same inputs
                 from hyperpocket_amd import ops
@@ -661,20 +705,39 @@ def main():
                     engine.emd_coef = emd_coef
                     line["breakdown"] = {"chamfer_only_ms_per_step": round(ms2, 4),
                                          "chamfer_only_clouds_per_s": round(args.batch / (ms2 * 1e-3), 2)}
-                    # ... and the same Chamfer-only iteration on the route the reference's untouched core/epoch_loops.py
-                    # takes with the drop-in modules (host-pinned inputs, torch KLD, 3 x .item(), torch.optim.Adam), then
-                    # with the documented one-line optimiser replacement
+                    # the same Chamfer+EMD step with EVERY kernel on its IEEE-fp32 form (fp32 MFMA / VALU fma; no f16 or bf16
+                    # pieces): the number behind the line's dtype "f32" read strictly
+                    with ops.strict_fp32():
+                        run(3)
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        run(args.steps)
+                        sync()
+                        ms32 = (time.perf_counter() - t1) / args.steps * 1e3
+                    run(2)      # (back on the default kernels before anything else is timed)
+                    torch.cuda.synchronize()
+                    line["breakdown"]["strict_fp32_ms_per_step"] = round(ms32, 4)
+                    line["breakdown"]["strict_fp32_clouds_per_s"] = round(args.batch / (ms32 * 1e-3), 2)
+                    line["breakdown"]["strict_fp32_what"] = ("the timed step with ops.strict_fp32(): conv stack, decoder forward, encoder "
+                                                             "backward chain + dW and the heads' forward on their fp32 kernels")
+                    # ... and the Chamfer-only iteration on the route the reference's untouched core/epoch_loops.py takes with the
+                    # drop-in modules (host-pinned inputs, torch KLD, 3 x .item(), torch.optim.Adam), then with the documented
+                    # one-line optimiser replacement
                     ms_t = dropin_route(args.batch, n_half, device, args.steps, "torch")
                     ms_f = dropin_route(args.batch, n_half, device, args.steps, "flat")
-                    line["breakdown"]["dropin_route"] = {
-                        "what": "core/epoch_loops.py:15-39 with FullModel + ChamferLoss + the caller's optimiser, Chamfer-only "
-                                "(the reference's training loss), inputs .to(device) from pinned host memory, 3 x .item() per step; median of three "
-                                "blocks of the timed iterations",
-                        "torch_optim_adam_ms_per_step": round(ms_t, 4),
-                        "torch_optim_adam_clouds_per_s": round(args.batch / (ms_t * 1e-3), 2),
-                        "flat_adam_ms_per_step": round(ms_f, 4),
-                        "flat_adam_clouds_per_s": round(args.batch / (ms_f * 1e-3), 2),
-                        "engine_over_dropin": round(ms_t / ms2, 3), "engine_over_dropin_flat_adam": round(ms_f / ms2, 3)}
+                    line["reference_loop"] = {
+                        "what": "core/epoch_loops.py:15-39 as the reference drives it, with FullModel + ChamferLoss dropped in: Chamfer-only "
+                                "loss (the reference's training loss), inputs .to(device) from pinned host memory, KLD in torch, 3 x .item() "
+                                "per iteration, the caller's optimiser; median of three blocks of the timed iterations",
+                        "clouds_per_s": round(args.batch / (ms_t * 1e-3), 2), "ms_per_step": round(ms_t, 4),
+                        "optimizer": "torch.optim.Adam(full_model.parameters(), lr=1e-4) as core/main.py:62-66 builds it",
+                        "with_flat_adam": {"clouds_per_s": round(args.batch / (ms_f * 1e-3), 2), "ms_per_step": round(ms_f, 4),
+                                           "optimizer": "hyperpocket_amd.optim.FlatAdam(full_model, lr=1e-4): the one-line replacement of INTEGRATION.md"},
+                        "engine_same_loss": {"clouds_per_s": round(args.batch / (ms2 * 1e-3), 2), "ms_per_step": round(ms2, 4),
+                                             "what": "TrainEngine.step, Chamfer-only, batch resident in HBM, no host sync"},
+                        "engine_over_reference_loop": round(ms_t / ms2, 3),
+                        "gap_ms": {"optimizer (torch Adam - FlatAdam)": round(ms_t - ms_f, 4),
+                                   "loop (FlatAdam route - engine: H2D copies, torch KLD, .item() syncs)": round(ms_f - ms2, 4)}}
             if world == 1 and not force_exchange and os.environ.get("HP_BENCH_NO_EXCHANGE_PROBE") is None:
                 # what the multi-rank step's bookkeeping costs before a byte crosses a link: the same step in a ONE-rank RCCL
                 # group in which every collective really runs (broadcast, factor gathers, in-place weight gather, both

@@ -1315,6 +1315,50 @@ def test_full_size_step_gradients_elementwise_vs_fp64_oracle(ref, state):
         ops.clear_grad_views()
 
 
+def test_sixty_engine_steps_track_the_oracle_no_worse_than_fp32_kernels(ref):
+    """End-to-end bound behind the per-layer error bars of the piece arithmetic: 60 consecutive engine steps
+    (Chamfer + KLD, Adam lr 1e-4) from the seeded init — the loss falls from ~4e6 to ~1e2 — against the oracle's fp32 CPU
+    steps on the same draws, once in the default arithmetic (f16 / bf16 piece products) and once with every kernel on its
+    fp32 form.  Training is chaotic: rounding differences of ANY fp32 implementation grow along the trajectory, so the
+    statement is comparative — the default arithmetic stays as close to the oracle as the all-fp32 kernels do (geometric
+    mean of the per-step relative loss difference within 3x) — plus absolute bars on the first steps."""
+    from hyperpocket_amd.core.engine import TrainEngine
+    from hyperpocket_amd import ops
+    g = golden("model_trained")
+    ex, mi, gt = (torch.from_numpy(g[k]) for k in ("existing", "missing", "gt"))
+    gen = torch.Generator().manual_seed(99)
+    torch.manual_seed(99)
+    draws = [(torch.stack([ref.generate_points(s + 1, gt.size(1)) for _ in range(gt.size(0))]),
+              torch.randn(gt.size(0), 128, generator=gen)) for s in range(60)]
+    P = ref.init_params(int(g["seed"]))
+    opt = ref.Adam(P)
+    want = np.array([ref.train_step(P, opt, ex, mi, gt, pts, eps)[0].item() for pts, eps in draws])
+    assert want[-1] < 1e-3 * want[0]              # it trains
+
+    def deviation(strict):
+        import contextlib
+        model = build_model(int(g["seed"]))
+        with (ops.strict_fp32() if strict else contextlib.nullcontext()):
+            eng = TrainEngine(model)
+            try:
+                got = [eng.step(ex.cuda(), mi.cuda(), gt.cuda(), s + 1, points=pts.cuda(), eps_noise=eps.cuda())["loss_all"].item()
+                       for s, (pts, eps) in enumerate(draws)]
+            finally:
+                eng.synchronize()
+                ops.clear_grad_views()
+        return np.abs(np.array(got) - want) / np.abs(want)
+
+    dev, dev32 = deviation(False), deviation(True)
+    np.set_printoptions(linewidth=200, precision=2)
+    print("default", dev)
+    print("fp32   ", dev32)
+    assert dev[0] <= 1e-5 and dev32[0] <= 1e-5
+    assert dev[:5].max() <= 1e-3 and dev32[:5].max() <= 1e-3
+    gm = lambda d: float(np.exp(np.log(np.maximum(d[1:], 1e-8)).mean()))
+    assert gm(dev) <= 3.0 * gm(dev32), (gm(dev), gm(dev32))
+    assert np.isfinite(dev).all() and dev.max() < 0.5
+
+
 def test_baseline_config4_hyperrec_full_size_step(ref):
     """BASELINE.json configs[3] per-GPU shape: Completion3D / HyperRec, partial cloud (B,2048,3), `missing` is the
     collated int 0 (datasets/shapenet_completion3d.py:41-48).  Parity with the oracle at full N on 4 clouds, then the
@@ -1412,6 +1456,54 @@ def test_baseline_config2_config3_per_gpu_step(ref, oracle_lib, B):
         assert moved["real_encoder.std_layer.weight"] == 0.0
         assert 0.5e-4 < moved["hyper_network.output.3.weight"] <= 1.01e-4 and 0.5e-4 < moved["random_encoder.conv.0.weight"] <= 1.01e-4
     finally:
+        ops.clear_grad_views()
+
+
+def test_engine_refuses_to_continue_after_backward_failed_behind_the_fused_heads_update():
+    """the heads' fused dW + Adam pass starts inside the hypernetwork's backward (HP_HEADS_EARLY, the default).
+    If the backward fails AFTER that node — here a hook on the latent's gradient raises, i.e. between the hypernetwork and the
+    encoders — the heads have taken an update no other parameter took.  The failed step is not counted, the next step()
+    raises instead of silently applying the heads' update a second time with the same bias-correction step, and loading a
+    checkpoint (model + optimiser) makes the engine usable again."""
+    from hyperpocket_amd.core.engine import TrainEngine
+    from hyperpocket_amd import ops
+    g = torch.Generator().manual_seed(21)
+    ex, mi = (torch.rand(2, 128, 3, generator=g) - 0.5).cuda(), (torch.rand(2, 128, 3, generator=g) - 0.5).cuda()
+    gt = torch.cat([ex, mi], 1)
+    pts, eps = (torch.rand(2, 256, 3, generator=g) * 2 - 1).cuda(), torch.randn(2, 128, generator=g).cuda()
+    model = build_model(8)
+    eng = TrainEngine(model)
+    assert eng.fused is not None and eng.fused.early
+    try:
+        eng.step(ex, mi, gt, 1, points=pts, eps_noise=eps)
+        msd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        osd = eng.optimizer_state_dict()
+        heads_before = model.hyper_network.output[3].weight.detach().clone()
+
+        class Boom(RuntimeError):
+            pass
+
+        fwd = model.forward
+
+        def forward_with_trap(*a, **k):
+            out = fwd(*a, **k)
+            model._last_latent.register_hook(lambda grad: (_ for _ in ()).throw(Boom("injected failure")))
+            return out
+        model.forward = forward_with_trap
+        with pytest.raises(Boom):
+            eng.step(ex, mi, gt, 1, points=pts, eps_noise=eps)
+        model.forward = fwd
+        assert eng.steps == 1                                        # the failed step is not counted ...
+        torch.cuda.synchronize()
+        assert not torch.equal(model.hyper_network.output[3].weight.detach(), heads_before)   # ... but the heads moved
+        with pytest.raises(RuntimeError, match="engine state inconsistent"):
+            eng.step(ex, mi, gt, 1, points=pts, eps_noise=eps)       # no silent second update
+        model.load_state_dict(msd)
+        eng.load_optimizer_state_dict(osd)
+        out = eng.step(ex, mi, gt, 1, points=pts, eps_noise=eps)     # usable again from the checkpoint
+        assert eng.steps == 2 and torch.isfinite(out["loss_all"]).item()
+    finally:
+        model.forward = fwd
         ops.clear_grad_views()
 
 
