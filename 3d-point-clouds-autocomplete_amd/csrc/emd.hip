@@ -95,6 +95,8 @@ inline int env_rows(const char* name) {
     const int v = e ? atoi(e) : 0;
     return (v == 1 || v == 2 || v == 4) ? v : 0;
 }
+// the final cost / gradient sweep with derived exponentials (match_entry2<.., DERIVE>): on unless HP_EMD_FINAL_DERIVE=0
+std::atomic<int> g_final_derive{[] { const char* e = getenv("HP_EMD_FINAL_DERIVE"); return (e && atoi(e) == 0) ? 0 : 1; }()};
 std::atomic<int> g_rows1{env_rows("HP_EMD_ROWS1_R")}, g_rows2{env_rows("HP_EMD_ROWS2_R")}, g_grad2{env_rows("HP_EMD_GRAD2_R") == 4 ? 0 : env_rows("HP_EMD_GRAD2_R")};
 
 struct Ctx {
@@ -374,12 +376,29 @@ __global__ __launch_bounds__(kThreads) void emd_rows2_kernel(Ctx c, int lev, flo
 // M(l,k) for the two candidates of a pair record = sum over levels, in level order, of
 //   ROW_IS_L: (exp(level*d) * ratioL_lev[row]) * ratioR_lev[cand]     (row = set1 point, candidates = set2)
 //   else    : (exp(level*d) * ratioL_lev[cand]) * ratioR_lev[row]
-template <bool ROW_IS_L>
+// DERIVE (the cost / gradient sweeps of the training path; never the `match` the API returns): the levels are exact powers of
+// 4 apart — l_j * d = 4 * (l_{j+1} * d) bit for bit — so exp2(l_j d) = exp2(l_{j+1} d)^4, and levels 0, 2, 4, 6 are formed as the
+// fourth power (two packed multiplies) of the hardware exponential of levels 1, 3, 5, 7: five v_exp_f32 per pair instead of nine.
+// A derived value carries ~5 ulp (4 x the exponential's + the two squarings') instead of 1.  Round 3 tried this in the LEVEL sweeps
+// as well and the auction amplified it past the parity bars; here nothing is downstream of the value: M moves by
+// <= 3.5e-7 relative, cost and gradients by less (tests: the cost error map's bars are unchanged, and the exact form stays
+// selectable: hp_emd_set_final_derive).
+template <bool ROW_IS_L, bool DERIVE>
 __device__ __forceinline__ f2 match_entry2(f2 d, const float (&row)[kLevels], const f32x16& lo, const f32x16& hi) {
     f2 acc = splat(0.f);
+    f2 ev[kLevels];
+#pragma unroll
+    for (int lev = kLevels - 1; lev >= 0; --lev) {
+        if (!DERIVE || lev == kLevels - 1 || (lev & 1)) {
+            ev[lev] = exp2_2(splat(level_l2e(lev)) * d);
+        } else {
+            const f2 sq = ev[lev + 1] * ev[lev + 1];
+            ev[lev] = sq * sq;
+        }
+    }
 #pragma unroll
     for (int lev = 0; lev < kLevels; ++lev) {
-        const f2 e = exp2_2(splat(level_l2e(lev)) * d);
+        const f2 e = ev[lev];
         const f2 cr = FINC(lo, hi, 3 + lev);
         // the level's term rides on an fma into the running sum (one rounding instead of the reference's two, i.e. a
         // slightly more accurate M; unlike the phase sweeps nothing downstream amplifies it: cost moves by ~1e-7 relative)
@@ -419,7 +438,7 @@ __global__ __launch_bounds__(kThreads) void emd_match_kernel(Ctx c, float* __res
         HP_SLOAD16(b0, p, 0x0);
         HP_SLOAD16(b1, p, 0x40);
         HP_PIN();
-        f2 v = match_entry2<true>(sqdist2(FINC(a0, a1, 0) - px2, FINC(a0, a1, 1) - py2, FINC(a0, a1, 2) - pz2), rL, a0, a1);
+        f2 v = match_entry2<true, false>(sqdist2(FINC(a0, a1, 0) - px2, FINC(a0, a1, 1) - py2, FINC(a0, a1, 2) - pz2), rL, a0, a1);
         if (ok) {
             out[(long)l * c.n] = v.x;
             if (l + 1 < cnt) out[(long)(l + 1) * c.n] = v.y;
@@ -429,7 +448,7 @@ __global__ __launch_bounds__(kThreads) void emd_match_kernel(Ctx c, float* __res
         HP_SLOAD16(a0, p, 0x0);
         HP_SLOAD16(a1, p, 0x40);
         HP_PIN();
-        v = match_entry2<true>(sqdist2(FINC(b0, b1, 0) - px2, FINC(b0, b1, 1) - py2, FINC(b0, b1, 2) - pz2), rL, b0, b1);
+        v = match_entry2<true, false>(sqdist2(FINC(b0, b1, 0) - px2, FINC(b0, b1, 1) - py2, FINC(b0, b1, 2) - pz2), rL, b0, b1);
         if (ok && l + 2 < cnt) {
             out[(long)(l + 2) * c.n] = v.x;
             if (l + 3 < cnt) out[(long)(l + 3) * c.n] = v.y;
@@ -440,6 +459,7 @@ __global__ __launch_bounds__(kThreads) void emd_match_kernel(Ctx c, float* __res
 
 // match-free cost + grad1:  cost_b = sum_{k,l} M(l,k) sqrt(d),  grad1[k] = sum_l M(l,k) (p_k-q_l)/max(|p_k-q_l|,1e-10)
 // (approxmatch.cu:215-255, 301-322 without the match tensor).  One lane per k, all l on the scalar path.
+template <bool DERIVE>
 __global__ __launch_bounds__(kThreads) void emd_cost_grad1_kernel(Ctx c, float* __restrict__ partials, float* __restrict__ grad1) {
     __shared__ float red[kThreads / 64];
     __shared__ float parts[kParts][4][kRowsPerWg];
@@ -456,9 +476,11 @@ __global__ __launch_bounds__(kThreads) void emd_cost_grad1_kernel(Ctx c, float* 
     auto work = [&](const f32x16& lo, const f32x16& hi) {
         const f2 ex = px2 - FINC(lo, hi, 0), ey = py2 - FINC(lo, hi, 1), ez = pz2 - FINC(lo, hi, 2);   // (x1 - x2), approxmatch.cu:312
         const f2 d2 = sqdist2(ex, ey, ez);       // squares: the sign of the difference does not change a bit
-        const f2 mv = match_entry2<true>(d2, rL, lo, hi);
+        const f2 mv = match_entry2<true, DERIVE>(d2, rL, lo, hi);
         const f2 w = mv * f2{__builtin_amdgcn_rsqf(fmaxf(d2.x, 1e-20f)), __builtin_amdgcn_rsqf(fmaxf(d2.y, 1e-20f))};
-        cost2 = __builtin_elementwise_fma(mv, f2{__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)}, cost2);
+        // M * sqrt(d) as (M / sqrt(d)) * d: the reciprocal root is needed for the gradient anyway (d = 0: w * 0 = 0 = M * sqrt(0))
+        cost2 = DERIVE ? __builtin_elementwise_fma(w, d2, cost2)
+                       : __builtin_elementwise_fma(mv, f2{__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)}, cost2);
         dx2 = __builtin_elementwise_fma(ex, w, dx2);
         dy2 = __builtin_elementwise_fma(ey, w, dy2);
         dz2 = __builtin_elementwise_fma(ez, w, dz2);
@@ -511,7 +533,7 @@ __global__ __launch_bounds__(kThreads) void emd_cost_grad1_kernel(Ctx c, float* 
 // match-free grad2[l] = sum_k M(l,k) (q_l-p_k)/max(|q_l-p_k|,1e-10)   (approxmatch.cu:260-300); with WITH_COST the
 // same sweep also yields the cost (sum over the same pairs, owned by l instead of k), so a training step that only
 // needs d cost / d xyz2 evaluates the match entries once.
-template <bool WITH_COST, int R>
+template <bool WITH_COST, int R, bool DERIVE>
 __global__ __launch_bounds__(kThreads) void emd_grad2_kernel(Ctx c, float* __restrict__ grad2, float* __restrict__ partials) {
     __shared__ float red[kThreads / 64];
     __shared__ float parts[kParts][4][kRowsPerWg * R];
@@ -541,10 +563,11 @@ __global__ __launch_bounds__(kThreads) void emd_grad2_kernel(Ctx c, float* __res
         for (int r = 0; r < R; ++r) {
             const f2 ex = qx2[r] - FINC(lo, hi, 0), ey = qy2[r] - FINC(lo, hi, 1), ez = qz2[r] - FINC(lo, hi, 2);
             const f2 d2 = sqdist2(ex, ey, ez);
-            const f2 mv = match_entry2<false>(d2, rR[r], lo, hi);
+            const f2 mv = match_entry2<false, DERIVE>(d2, rR[r], lo, hi);
             const f2 w = mv * f2{__builtin_amdgcn_rsqf(fmaxf(d2.x, 1e-20f)), __builtin_amdgcn_rsqf(fmaxf(d2.y, 1e-20f))};
             if (WITH_COST)
-                cost2[r] = __builtin_elementwise_fma(mv, f2{__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)}, cost2[r]);
+                cost2[r] = DERIVE ? __builtin_elementwise_fma(w, d2, cost2[r])      // (M / sqrt(d)) * d, see emd_cost_grad1_kernel
+                                  : __builtin_elementwise_fma(mv, f2{__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)}, cost2[r]);
             sx2[r] = __builtin_elementwise_fma(ex, w, sx2[r]);
             sy2[r] = __builtin_elementwise_fma(ey, w, sy2[r]);
             sz2[r] = __builtin_elementwise_fma(ez, w, sz2[r]);
@@ -782,6 +805,10 @@ HP_API int hp_emd_set_rows_per_lane(int rows1, int rows2, int grad2) {
     return 0;
 }
 
+// The training path's final cost / gradient sweep with four of its nine exponentials per pair derived (1, default) or all nine
+// from v_exp_f32 (0); returns the previous setting.  `match` as hp_approxmatch* return it is never derived.
+HP_API int hp_emd_set_final_derive(int on) { return g_final_derive.exchange(on != 0); }
+
 // replaces approxmatch(...)  structural_loss.cpp:11 / approxmatch.cu:330-338 — the reference's exact argument list:
 // match (b,m,n) and temp (b,2(n+m)) are the only buffers.  temp ends as cloud i's [remainL | remainR | ratioL | ratioR].
 HP_API int hp_approxmatch(int b, int n, int m, const float* xyz1, const float* xyz2, float* match, float* temp, hipStream_t stream) {
@@ -866,22 +893,29 @@ int emd_forward_impl(int b, int n, int m, const float* xyz1, const float* xyz2, 
         if (rc) return rc;
     }
     const int nb = (n + kRowsPerWg - 1) / kRowsPerWg, mb = (m + kRowsPerWg - 1) / kRowsPerWg;
+    const bool derive = g_final_derive.load(std::memory_order_relaxed) != 0;
     if (grad2) {
         const int genv = g_grad2.load(std::memory_order_relaxed);
         const int mbr = (m + 2 * kRowsPerWg - 1) / (2 * kRowsPerWg);
         // two rows per lane when that still leaves >= 2 waves per SIMD (as in run_levels; -0.01 ms at B=64, N=2048)
         const int gr = genv ? genv : ((long)b * mbr * (kThreads / 64) >= 2048 ? 2 : 1);
         if (gr == 2) {
-            hipLaunchKernelGGL((emd_grad2_kernel<true, 2>), dim3(mbr, b), dim3(kThreads), 0, stream, c, grad2, partials);
+            if (derive) hipLaunchKernelGGL((emd_grad2_kernel<true, 2, true>), dim3(mbr, b), dim3(kThreads), 0, stream, c, grad2, partials);
+            else hipLaunchKernelGGL((emd_grad2_kernel<true, 2, false>), dim3(mbr, b), dim3(kThreads), 0, stream, c, grad2, partials);
             hipLaunchKernelGGL(emd_cost_finish_kernel, dim3(b), dim3(256), 0, stream, partials, mbr, cost);
         } else {
-            hipLaunchKernelGGL((emd_grad2_kernel<true, 1>), dim3(mb, b), dim3(kThreads), 0, stream, c, grad2, partials);
+            if (derive) hipLaunchKernelGGL((emd_grad2_kernel<true, 1, true>), dim3(mb, b), dim3(kThreads), 0, stream, c, grad2, partials);
+            else hipLaunchKernelGGL((emd_grad2_kernel<true, 1, false>), dim3(mb, b), dim3(kThreads), 0, stream, c, grad2, partials);
             hipLaunchKernelGGL(emd_cost_finish_kernel, dim3(b), dim3(256), 0, stream, partials, mb, cost);
         }
-        if (grad1) hipLaunchKernelGGL(emd_cost_grad1_kernel, dim3(nb, b), dim3(kThreads), 0, stream, c, partials, grad1);
         // (the second sweep's partials are unused: cost was already reduced, in stream order, by the finish kernel)
+        if (grad1) {
+            if (derive) hipLaunchKernelGGL(emd_cost_grad1_kernel<true>, dim3(nb, b), dim3(kThreads), 0, stream, c, partials, grad1);
+            else hipLaunchKernelGGL(emd_cost_grad1_kernel<false>, dim3(nb, b), dim3(kThreads), 0, stream, c, partials, grad1);
+        }
     } else {
-        hipLaunchKernelGGL(emd_cost_grad1_kernel, dim3(nb, b), dim3(kThreads), 0, stream, c, partials, grad1);
+        if (derive) hipLaunchKernelGGL(emd_cost_grad1_kernel<true>, dim3(nb, b), dim3(kThreads), 0, stream, c, partials, grad1);
+        else hipLaunchKernelGGL(emd_cost_grad1_kernel<false>, dim3(nb, b), dim3(kThreads), 0, stream, c, partials, grad1);
         hipLaunchKernelGGL(emd_cost_finish_kernel, dim3(b), dim3(256), 0, stream, partials, nb, cost);
     }
     HP_RETURN_LAST_ERROR();
@@ -897,6 +931,8 @@ HP_API int hp_emd_backward(int b, int n, int m, const float* xyz1, const float* 
     HP_CHECK_ARG(ws && grad2 && b <= 65535);
     const WsLayout L = ws_layout(n, m);
     Ctx c{n, m, L.NP, L.MP, xyz1, xyz2, nullptr, const_cast<float*>(ws), L.plp, L.prp, L.rr, L.flp, L.frp, L.per_cloud};
-    hipLaunchKernelGGL((emd_grad2_kernel<false, 1>), dim3((m + kRowsPerWg - 1) / kRowsPerWg, b), dim3(kThreads), 0, stream, c, grad2, nullptr);
+    const dim3 grid((m + kRowsPerWg - 1) / kRowsPerWg, b);
+    if (g_final_derive.load(std::memory_order_relaxed)) hipLaunchKernelGGL((emd_grad2_kernel<false, 1, true>), grid, dim3(kThreads), 0, stream, c, grad2, nullptr);
+    else hipLaunchKernelGGL((emd_grad2_kernel<false, 1, false>), grid, dim3(kThreads), 0, stream, c, grad2, nullptr);
     HP_RETURN_LAST_ERROR();
 }

@@ -13,7 +13,7 @@
  *      approxmatch.cu:334-337; its nndistance launchers check nothing, nndistance.cu:131-160).
  * Layouts are the reference's: point sets (b, n, 3) fp32 contiguous, indices int32.
  *
- * TEST HOOKS.  hp_emd_set_rows_per_lane, hp_encoder_backward_set_fused, hp_encoder_backward_set_chain_f16, hp_hypernet_set_heads_stream, hp_conv_split_set, hp_skinny_set_enabled,
+ * TEST HOOKS.  hp_emd_set_rows_per_lane, hp_emd_set_final_derive, hp_encoder_backward_set_fused, hp_encoder_backward_set_chain_f16, hp_hypernet_set_heads_stream, hp_conv_split_set, hp_skinny_set_enabled,
  * hp_target_fused_set_f16 (and hp_conv_presplit_set below) flip PROCESS-WIDE switches that select between implementations of
  * the same result; they exist so that the parity tests can hold every implementation against the oracle in one process.  They
  * are plain globals: not thread-safe, not per-stream, not meant to be called while another host thread is inside the library.
@@ -62,6 +62,13 @@ int hp_approxmatch_ws(int b, int n, int m, const float* xyz1, const float* xyz2,
  * for bit; tests/test_structural_losses_gpu.py). */
 /* [test hook: process-wide, not thread-safe — see the header comment] */
 int hp_emd_set_rows_per_lane(int rows1, int rows2, int grad2);
+/* The match-free cost / gradient sweep (hp_emd_forward*, hp_emd_backward) evaluates the nine per-level exponentials of a point
+ * pair; the levels are exact powers of 4 apart, so four of them can be formed as the fourth power of their neighbour's (two
+ * multiplies instead of v_exp_f32; ~5 ulp instead of 1 on a value nothing is downstream of).  1 (default; environment
+ * HP_EMD_FINAL_DERIVE=0 turns it off at load time): derived; 0: all nine from the hardware exponential.  Returns the previous
+ * setting.  The level sweeps and the `match` tensor hp_approxmatch / hp_approxmatch_ws return are never derived. */
+/* [test hook: process-wide, not thread-safe — see the header comment] */
+int hp_emd_set_final_derive(int on);
 
 /* Match-free EMD (what match_cost.py:9-46 computes through ApproxMatch + MatchCost + MatchCostGrad, without ever
  * writing the (b,m,n) match tensor): cost (b,) plus whichever of grad1 = d cost/d xyz1, grad2 = d cost/d xyz2 the

@@ -413,6 +413,44 @@ def test_emd_rows_per_lane_instances_agree_bit_for_bit(backend, rows_per_lane, b
                     assert torch.equal(x, y), (r1, r2, g2, i)
 
 
+def test_emd_final_sweep_derived_exponentials_vs_all_nine_from_hardware(oracle_lib):
+    """The match-free cost / gradient sweep forms four of its nine per-level exponentials as the fourth power of their
+    neighbour's (emd.hip match_entry2<., DERIVE>; default on).  Against the same sweep with all nine from v_exp_f32, over the
+    regimes of the cost error map at N = 2048 plus ragged small shapes: cost within 1e-6 relative, both gradients within 2e-6
+    of their scale; and the exact form still equals the materialising path's cost to its old bar.  (Against the oracle the
+    derived form is what test_emd_cost_error_distribution_at_full_size and the full-size call tests measure, at unchanged bars.)"""
+    from hyperpocket_amd._lib import load_library
+    lib = load_library()
+    cases = [(_clouds(5, 3, 200, 330)), (_clouds(6, 5, 64, 64))]
+    for gt, rec in _emd_regimes().values():
+        cases.append((gt[:6], rec[:6]))
+    worst_c = worst_g = 0.0
+    prev = lib.hp_emd_set_final_derive(1)
+    try:
+        for a, c in cases:
+            lib.hp_emd_set_final_derive(1)
+            cost_d, g1_d, g2_d = _emd_forward(a, c, True, True)
+            cost_b, _, g2_b = _emd_forward(a, c, False, True)          # the training call's shape: cost rides on the grad2 sweep
+            lib.hp_emd_set_final_derive(0)
+            cost_e, g1_e, g2_e = _emd_forward(a, c, True, True)
+            assert torch.equal(g2_d, g2_b)
+            mass = cost_e > 1e-3
+            rel = ((cost_d - cost_e).abs() / cost_e.abs().clamp_min(1e-30))[mass]
+            relb = ((cost_b - cost_e).abs() / cost_e.abs().clamp_min(1e-30))[mass]
+            assert rel.numel() == 0 or max(rel.max().item(), relb.max().item()) <= 1e-6, (rel.max().item(), relb.max().item())
+            assert ((cost_d - cost_e).abs()[~mass] <= 1e-6).all()
+            for gd, ge in ((g1_d, g1_e), (g2_d, g2_e)):
+                scale = ge.abs().max().item()
+                err = (gd - ge).abs().max().item()
+                assert err <= 2e-6 * scale + 1e-12, (err, scale)
+                worst_g = max(worst_g, err / max(scale, 1e-30))
+            if rel.numel():
+                worst_c = max(worst_c, rel.max().item())
+        print(f"\nderived vs exact final sweep: worst cost rel diff {worst_c:.2e}, worst gradient diff / scale {worst_g:.2e}")
+    finally:
+        lib.hp_emd_set_final_derive(prev)
+
+
 @pytest.mark.parametrize("B", [64, 32])
 def test_emd_training_call_full_size_vs_oracle(oracle_lib, B):
     """The call core/engine.py makes at the bench shape — hp_emd_forward(B=64, N=2048, grad1=NULL, grad2 != NULL), i.e.
