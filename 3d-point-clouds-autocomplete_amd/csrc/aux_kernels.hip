@@ -76,8 +76,11 @@ constexpr int kSliceMaxPts = 8192;
 // device speed: the law of the reference, other draws).  PLANES = true: the caller supplies the candidate sequence
 // planes (B, R, 4) float64 = (params, bias) of HyperPlane — e.g. the planes numpy's generator gives the reference — and
 // every point is classified as HyperPlane.check_point does it (dataset_generator.py:10-11): float64
-// dot(point, params) + bias, products rounded before their adds; the accepted candidate's index is returned, so the
-// result is the reference's own split, bit for bit.
+// dot(point, params) + bias, products rounded before their adds; the accepted candidate's index is returned.  The result is
+// the reference's own split whenever no point lies within float64 rounding of a candidate plane: numpy evaluates that dot
+// through BLAS (dgemv), whose use of fma and summation order is the library's choice, so a point within ~1 ulp (1e-16
+// relative) of the plane could classify differently there — the six fixture clouds (tests/golden/slicer.npz, up to 5518
+// candidates each) reproduce index and both parts exactly.
 template <bool PLANES>
 __global__ __launch_bounds__(256) void slice_kernel(int N, int target, const float* __restrict__ pts, unsigned long long seed,
                                                     int max_rounds, const double* __restrict__ planes, int R,
@@ -127,7 +130,8 @@ __global__ __launch_bounds__(256) void slice_kernel(int N, int target, const flo
             bias = fx * p0x + fy * p0y + fz * p0z;                 // HyperPlane(cp, np.dot(cp, points[0]))
         }
         int cnt = 0;
-        for (int i = lane; i < N; i += 64) cnt += under_of(i, nx, ny, nz, bias);
+        if (have)      // (wave-uniform; a wave past the last candidate of the list has nothing to count)
+            for (int i = lane; i < N; i += 64) cnt += under_of(i, nx, ny, nz, bias);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
         if (lane == 0) wave_cnt[wid] = have ? cnt : -1;

@@ -89,7 +89,7 @@ __device__ __forceinline__ void act8(const unsigned char* rowp, bool pfmt, int c
 #define HP_EB_GWG 4096
 #endif
 #ifndef HP_EB_GEB
-#define HP_EB_GEB 8
+#define HP_EB_GEB 4
 #endif
 constexpr int kGatherRowWgs = HP_EB_GWG;    // persistent row workgroups per encoder (gather launch)
 
@@ -175,7 +175,13 @@ __global__ __launch_bounds__(512) void enc_bwd_prep_kernel(const HpEncBwdArgs a)
 // Workgroups [0, kGatherRowWgs): four rows at a time, ONE WAVE per row (cloud b, slot u): delta4[row] = (h4[row] > 0) * sum over
 // the row's channels, ascending, of dg[b,c] * W5[c,:]; a lane owns 8 of the 512 columns; rows in [cnt, ru32(cnt)) are
 // written as zeros (the matrix-core launches run on whole 32-row blocks).
-__global__ __launch_bounds__(256) void enc_bwd_gather_kernel(const HpEncBwdArgs a) {
+// Round 5: four W5 rows in flight per wave (HP_EB_GEB, was 8) at four workgroups per CU (98 VGPRs, no spill; was 148 / three):
+// the launch is a chain of dependent memory round trips, occupancy hides them — 125 -> 108 us in the step's trace (the step
+// itself does not move: the region is bandwidth-bound beside the heads' dW + Adam pass).
+#ifndef HP_EB_GOCC
+#define HP_EB_GOCC 4
+#endif
+__global__ __launch_bounds__(256, HP_EB_GOCC) void enc_bwd_gather_kernel(const HpEncBwdArgs a) {
     __shared__ int sarg[256];
     __shared__ float sdg[256];
     __shared__ float sus[256][4];

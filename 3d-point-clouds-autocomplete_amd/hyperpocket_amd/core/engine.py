@@ -236,6 +236,7 @@ class TrainEngine:
         self._deferred_losses = None
         import os as _os
         self._join_early = _os.environ.get("HP_HEADS_JOIN_AT_STEP_END", "0") == "1"
+        self._loss_side_stream = _os.environ.get("HP_LOSS_SIDE_STREAM", "1") != "0"
         # The model only holds WEAK references to its engine (a dropped engine must not stay pinned — with its four flat
         # 173 MB buffers — by the model's hooks), and a new engine on the same model takes the hooks over.
         prev = model.__dict__.get("_engine_ref")
@@ -403,7 +404,7 @@ class TrainEngine:
             kld = torch.empty((), **f32)
             g_lv, g_mu = torch.empty_like(lv_c), torch.empty_like(mu_c)
         side = None
-        if self.emd_coef:
+        if self.emd_coef and self._loss_side_stream:
             # Chamfer / KLD (VALU-bound, ~0.15 ms) and the EMD sweeps (2 waves/SIMD, VALU pipe ~60 % busy) are
             # independent consumers of the model outputs: the small ones go to a side stream and fill the EMD's idle
             # issue slots
@@ -437,7 +438,7 @@ class TrainEngine:
             # c_emd * (its term) onto the Chamfer gradient the side stream left in g_rec, behind an event on that stream
             # (which also joins the KLD gradients): no axpy launch, no separate stream join
             call("hp_emd_forward_acc", B, N, N, gt_c, rec_c, temp, ws, epart, cost, g_rec, float(c_emd), current_stream(dev),
-                 ctypes.c_void_p(side.cuda_stream))
+                 ctypes.c_void_p(side.cuda_stream) if side is not None else None)
         terms = torch.empty((4,), **f32)
         # the scalar loss terms are nobody's input: their launch is deferred behind the backward's launches (step()), so it
         # does not sit between the EMD and the first backward kernel

@@ -251,7 +251,13 @@ int hp_gemm_pp_partials(long M, int N, int K, const float* ws, float* cmax, int*
  * cloud carry gradient below the max-pool: their activations are copied out of fwd_ws (the workspace
  * hp_encoder_forward ran in, untouched since) or, with fwd_ws = NULL, recomputed from x.  dedup != 0: channels that
  * peak at the same point share one row (their gradients add), so the layers below run on the DISTINCT critical
- * points, about a third of B*512; same gradients up to fp32 summation order. */
+ * points, about a third of B*512; same gradients up to fp32 summation order.
+ * fwd_ws is declared const because the call never changes the VALUES it holds, but the layered path (dedup == 0, or the fused
+ * path switched off) rewrites their REPRESENTATION in place: hidden activations the forward left in the piece format are
+ * converted to fp32 rows and the workspace's format word is updated (as hp_encoder_workspace_to_f32 does).  Consequences for a
+ * foreign caller: do not run two backward calls over the same workspace concurrently on different streams, and a workspace
+ * not produced by hp_encoder_forward* must carry a valid format word (call hp_encoder_workspace_to_f32 semantics: fp32 rows +
+ * the word hp_encoder_forward writes).  The autograd bridge (ops.py) uses each workspace for exactly one backward. */
 long hp_encoder_backward_workspace_floats(int B, int out_size);
 int hp_encoder_backward(int B, int Np, const float* x, const HpEncoderWeights* w, int out_size, int is_vae,
                         const float* eps, const int* argidx, const float* g, const float* f, const float* lv,

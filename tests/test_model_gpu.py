@@ -253,8 +253,13 @@ def test_conv_stack_split_f16_is_as_close_to_fp64_as_the_fp32_chain(B, Np, xscal
             torch.nn.init.uniform_(params[5 + i], -0.05 * wscale, 0.05 * wscale)
     x = ((torch.rand(B, Np, 3, device="cuda") - 0.5) * xscale).contiguous()
     got = {s: _conv_stack_from_workspace(B, Np, x, params, s) for s in (True, False)}
-    stats = {True: [], False: []}
-    for s in (True, False):
+    variants = [True, False]
+    if Np % 128 == 0:
+        # round 3's path (fp32 activations split in the consumer, HP_CONV_PRESPLIT=0) keeps ITS bars: 1.5x / 2.5x
+        got["r3"] = _conv_stack_from_workspace(B, Np, x, params, True, presplit=False)
+        variants.append("r3")
+    stats = {v: [] for v in variants}
+    for s in variants:
         hs, g, argidx = got[s]
         prev = x.view(B * Np, 3)
         for l in range(4):
@@ -299,6 +304,10 @@ def test_conv_stack_split_f16_is_as_close_to_fp64_as_the_fp32_chain(B, Np, xscal
         else:
             assert rms_s <= 1.5 * rms_c + 1e-9 and max_s <= 2.5 * max_c + 1e-9, msg
         assert max_s <= 2e-6, msg
+        if "r3" in stats and l > 0:
+            rms_o, max_o = stats["r3"][l]
+            assert rms_o <= 1.5 * rms_c + 1e-9 and max_o <= 2.5 * max_c + 1e-9 and max_o <= 2e-6, \
+                f"layer {l + 1}, HP_CONV_PRESPLIT=0: rms {rms_o:.3e} max {max_o:.3e} | fp32 chain rms {rms_c:.3e} max {max_c:.3e}"
 
 
 def test_conv_stack_split_outlier_point_costs_only_its_tile():
@@ -1010,11 +1019,20 @@ def _caller_step(epoch, model, opt, batch, device, loss_fn, loss_coef=0.05):
     return loss_all.item(), loss_kld.item(), loss_r.item(), existing.detach().cpu().numpy(), rec.detach().cpu().numpy()
 
 
+@pytest.mark.parametrize("arithmetic", ["default", "strict_fp32"])
 @pytest.mark.parametrize("paired", [True, False])
-def test_train_steps_vs_reference_golden(paired):
+def test_train_steps_vs_reference_golden(paired, arithmetic):
     """Three Adam steps of the drop-in route (FullModel + ChamferLoss + torch.optim.Adam, driven as
     core/epoch_loops.py:15-39 drives them) vs the reference's own train_epoch — with the two encoders as one paired node
-    (batched conv launches, ops.EncoderPairFunction) and as two nodes on two streams."""
+    (batched conv launches, ops.EncoderPairFunction) and as two nodes on two streams; in the default arithmetic and with every
+    kernel on its fp32 form."""
+    import contextlib
+    from hyperpocket_amd import ops
+    with (ops.strict_fp32() if arithmetic == "strict_fp32" else contextlib.nullcontext()):
+        _train_steps_vs_reference_golden(paired)
+
+
+def _train_steps_vs_reference_golden(paired):
     from hyperpocket_amd.losses.champfer_loss import ChamferLoss
     g = golden("train_steps")
     model = build_model(int(g["seed"]))
