@@ -553,6 +553,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline/breakdown side measurements")
     ap.add_argument("--roofline-minimal", action="store_true", help="the roofline kernel alone (200 warm-up + 100 timed launches): the command of the rocprofv3 passes")
+    ap.add_argument("--roofline-emd-only", action="store_true",
+                    help="the dominant family alone: the hp_emd_forward calls `roofline` times (10 warm-up + 20 timed) — the command of its rocprofv3 pass")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the roofline leg (the dominant kernel at the step's shape) and print its object: the "
                          "command profiles/ pairs with `rocprofv3 --kernel-trace --stats`")
@@ -566,6 +568,10 @@ def main():
         return
     if args.roofline_minimal:
         print(json.dumps({"roofline": roofline_widest_matrix_kernel(args.batch, args.points // 2, minimal=True)}), flush=True)
+        return
+    if args.roofline_emd_only:
+        torch.cuda.set_device(0)
+        print(json.dumps({"roofline": roofline_emd(args.batch, args.points)}), flush=True)
         return
     if args.roofline_only:
         torch.cuda.set_device(0)

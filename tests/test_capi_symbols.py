@@ -81,3 +81,54 @@ def test_product_package_never_imports_the_oracle():
         assert "structural_losses_ref" not in src and "hyperpocket_ref" not in src, path
     for path in glob.glob(os.path.join(PKG_DIR, "csrc", "*")):
         assert "oracle/" not in open(path).read(), path
+
+
+def test_strict_fp32_flips_every_piece_arithmetic_switch_and_restores_it(lib):
+    """ops.strict_fp32(): inside the block every kernel family that forms fp32 products from f16 / bf16 pieces is on its fp32
+    form (the library's process-wide switches read 0); afterwards each switch holds what it held before.  Host-only calls."""
+    from hyperpocket_amd import ops
+    loaded = ops.load_library()
+    before = []
+    for name in ops._PIECE_SWITCHES:
+        fn = getattr(loaded, name)
+        was = fn(1)
+        fn(was)
+        before.append(was)
+    with ops.strict_fp32():
+        for name in ops._PIECE_SWITCHES:
+            fn = getattr(loaded, name)
+            inside = fn(0)
+            assert inside == 0, name
+    for name, was in zip(ops._PIECE_SWITCHES, before):
+        fn = getattr(loaded, name)
+        now = fn(was)
+        assert now == was, (name, now, was)
+    # the final-sweep derivation of the EMD is its own switch (not an fp32-vs-pieces question): default on
+    assert loaded.hp_emd_set_final_derive(1) == 1
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference tree (build container only)")
+def test_no_same_named_python_file_is_the_references_text():
+    """The boundary forces names, sizes, registration order — not the text (three model shells were 56-81 % the
+    reference's lines).  Share of the reference file's code lines found verbatim in the same-named file here: the model
+    shells under 30 %, every other same-named file under 40 % (tools/line_overlap.py is the measure)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("line_overlap", os.path.join(ROOT, "tools", "line_overlap.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    pkg = os.path.join(PKG_DIR, "hyperpocket_amd")
+    seen = 0
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            mine = os.path.join(root, f)
+            rel = os.path.relpath(mine, pkg)
+            ref = os.path.join("/root/reference", rel)
+            if not f.endswith(".py") or not os.path.exists(ref):
+                continue
+            r, m = mod.code_lines(ref), set(mod.code_lines(mine))
+            if len(r) < 10:
+                continue
+            share = sum(1 for ln in r if ln in m) / len(r)
+            seen += 1
+            assert share < (0.30 if rel.startswith("model/") else 0.40), (rel, round(share, 2))
+    assert seen >= 8

@@ -98,7 +98,7 @@ def main():
         (f"emd_rows1_kernel<true, true, {r1}>", 8, r1, 16),
         # (the last level's phase 3, emd_rows1_kernel<true, false, .>, is not launched on this path: no reader)
         (f"emd_rows2_kernel<{r2}>", 9, r2, 16),
-        (f"emd_grad2_kernel<true, {g2}>", 1, g2, 4),
+        (f"emd_grad2_kernel<true, {g2}, true>", 1, g2, 4),      # (the final sweep with derived exponentials: round 5)
     ]
     total, rows_out = 0, []
     for name, launches, R, per_iter in plan:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): the numbers and rocprof summaries committed under profiles/ (per round: HP_ROUND, default r04).
+# Runs on the GPU box (gpurun): the numbers and rocprof summaries committed under profiles/ (per round: HP_ROUND, default r05).
 : "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"
 R=$GRAFT_REPO_ROOT; O="$R/gpurun_out/final"; rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
@@ -14,6 +14,7 @@ pmc() { d=$1; c=$2; shift; shift; timeout 600 rocprofv3 --kernel-trace --pmc $c 
 STEP="--steps 5 --warmup 2 --no-extras --no-cpu-baseline"
 prof step $STEP
 prof roof --roofline-minimal
+prof roof_emd --roofline-emd-only
 prof stress --workload chamfer-stress --steps 5 --warmup 2 --no-extras
 for c in FETCH_SIZE WRITE_SIZE; do
   pmc roof_pmc_$c $c --roofline-minimal

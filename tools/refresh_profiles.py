@@ -6,7 +6,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 F = os.path.join(R, "gpurun_out", "final")
 P = os.path.join(R, "profiles")
 py = sys.executable
-RD = os.environ.get("HP_ROUND", "r04")
+RD = os.environ.get("HP_ROUND", "r05")
 RN = RD.lstrip("r0")
 
 
@@ -41,6 +41,9 @@ subprocess.check_call([py, summ, os.path.join(F, "step"), os.path.join(P, f"{RD}
 subprocess.check_call([py, summ, os.path.join(F, "roof"), os.path.join(P, f"{RD}_roofline_kernel_stats.md"),
                        f"Round {RN} — roofline launch alone: rocprofv3 --kernel-trace --stats -- python3 bench.py --roofline-minimal "
                        "(encoder conv5: M=65536, N=K=512; 200 warm-up + 100 timed launches, back to back)", "1"])
+subprocess.check_call([py, summ, os.path.join(F, "roof_emd"), os.path.join(P, f"{RD}_roofline_emd_kernel_stats.md"),
+                       f"Round {RN} — the `roofline` object's command alone: rocprofv3 --kernel-trace --stats -- python3 bench.py --roofline-emd-only "
+                       "(hp_emd_forward at B=64, n=m=2048: 10 warm-up + 20 timed calls; per call 1 init + 9 emd_rows1 + 9 emd_rows2 + 1 emd_grad2 + 1 finish)", "30"])
 subprocess.check_call([py, summ, os.path.join(F, "stress"), os.path.join(P, f"{RD}_chamfer_n8192_kernel_stats.md"),
                        f"Round {RN} — BASELINE configs[4] per-GPU shape: rocprofv3 --kernel-trace --stats -- python3 bench.py --workload "
                        "chamfer-stress --steps 5 --warmup 2 --no-extras (B=64, N=8192, Chamfer forward+backward; 7 steps)", "7"])
