@@ -228,10 +228,11 @@ def cpu_baseline(n_half, emd_coef, sample_b=4, timed_steps=2, full_b=64):
         for n_thr in sorted({min(64, host_cores), host_cores}):
             if n_thr <= threads:
                 continue
-            if out["more_threads"] and out["more_threads"][-1]["s_per_step"] > 1.5 * best and not os.environ.get("HP_BENCH_ALL_CORES"):
+            if out["more_threads"] and out["more_threads"][-1]["s_per_step"] >= dt and not os.environ.get("HP_BENCH_ALL_CORES"):
                 out["more_threads"].append({"cores": n_thr, "value": None,
-                                            "sample": "skipped: the previous leg was already >1.5x slower than 16 threads "
-                                                      "(HP_BENCH_ALL_CORES=1 forces it)"})
+                                            "sample": f"skipped: {out['more_threads'][-1]['cores']} threads were already no faster than {threads} "
+                                                      "(HP_BENCH_ALL_CORES=1 forces it; measured in round 5: 70.7 s/step = 0.057 clouds/s at "
+                                                      "256 threads, profiles/r05_cpu_baseline_threads.json)"})
                 continue
             use(n_thr)
             dt_n = leg(sample_b, 1)
