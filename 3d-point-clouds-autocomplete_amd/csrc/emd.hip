@@ -28,6 +28,8 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 
 // (Round 3's derived-exponential experiment — e(j) = e(j+1)^4, -0.08 ms per step, fails the parity bars — lives as a patch in
 // tools/micro/emd_derive.patch, not in the shipped library: DESIGN.md 7b.)
@@ -95,6 +97,8 @@ inline int env_rows(const char* name) {
     const int v = e ? atoi(e) : 0;
     return (v == 1 || v == 2 || v == 4) ? v : 0;
 }
+// hp_emd_forward* as two chains of half the clouds on two streams (2) or one chain (1): emd_forward_impl
+std::atomic<int> g_chains{[] { const char* e = getenv("HP_EMD_CHAINS"); const int v = e ? atoi(e) : 2; return v == 1 ? 1 : 2; }()};
 // the final cost / gradient sweep with derived exponentials (match_entry2<.., DERIVE>): on unless HP_EMD_FINAL_DERIVE=0
 std::atomic<int> g_final_derive{[] { const char* e = getenv("HP_EMD_FINAL_DERIVE"); return (e && atoi(e) == 0) ? 0 : 1; }()};
 std::atomic<int> g_rows1{env_rows("HP_EMD_ROWS1_R")}, g_rows2{env_rows("HP_EMD_ROWS2_R")}, g_grad2{env_rows("HP_EMD_GRAD2_R") == 4 ? 0 : env_rows("HP_EMD_GRAD2_R")};
@@ -809,6 +813,12 @@ HP_API int hp_emd_set_rows_per_lane(int rows1, int rows2, int grad2) {
 // from v_exp_f32 (0); returns the previous setting.  `match` as hp_approxmatch* return it is never derived.
 HP_API int hp_emd_set_final_derive(int on) { return g_final_derive.exchange(on != 0); }
 
+// hp_emd_forward* as two chains of half the clouds on two streams (2, default) or as one chain (1); returns the previous setting.
+HP_API int hp_emd_set_chains(int chains) {
+    HP_CHECK_ARG(chains == 1 || chains == 2);
+    return g_chains.exchange(chains);
+}
+
 // replaces approxmatch(...)  structural_loss.cpp:11 / approxmatch.cu:330-338 — the reference's exact argument list:
 // match (b,m,n) and temp (b,2(n+m)) are the only buffers.  temp ends as cloud i's [remainL | remainR | ratioL | ratioR].
 HP_API int hp_approxmatch(int b, int n, int m, const float* xyz1, const float* xyz2, float* match, float* temp, hipStream_t stream) {
@@ -879,11 +889,9 @@ HP_API int hp_emd_forward_acc(int b, int n, int m, const float* xyz1, const floa
 }
 
 namespace {
-int emd_forward_impl(int b, int n, int m, const float* xyz1, const float* xyz2, float* temp, float* ws, float* partials,
-                     float* cost, float* grad1, float* grad2, float acc_scale, hipStream_t stream, hipStream_t after) {
-    HP_CHECK_ARG(b >= 0 && n > 0 && m > 0);
-    if (b == 0) return 0;
-    HP_CHECK_ARG(xyz1 && xyz2 && temp && ws && partials && cost && b <= 65535);
+// ONE chain: the 18 level sweeps + the final sweep of `b` clouds, launch behind launch on `stream`.
+int emd_forward_chain(int b, int n, int m, const float* xyz1, const float* xyz2, float* temp, float* ws, float* partials,
+                      float* cost, float* grad1, float* grad2, float acc_scale, hipStream_t stream, hipStream_t after) {
     Ctx c;
     int rc = run_levels(b, n, m, xyz1, xyz2, temp, ws, &c, stream, false);   // temp is scratch here
     if (rc) return rc;
@@ -919,6 +927,64 @@ int emd_forward_impl(int b, int n, int m, const float* xyz1, const float* xyz2, 
         hipLaunchKernelGGL(emd_cost_finish_kernel, dim3(b), dim3(256), 0, stream, partials, nb, cost);
     }
     HP_RETURN_LAST_ERROR();
+}
+
+
+// Round 5: the clouds are independent, but a launch is not — each of the 19 dependent launches pays its ramp, prologue, epilogue
+// and tail with every wave of the chip in lockstep (at B = 64 the grid is ONE round of workgroups), ~8 us per launch that the
+// same launches on several times the clouds amortise (tools/emd_launch_bound.py: 1.371 ms at 64 clouds, 1.217 per 64 at 576).
+// So the call runs as TWO chains of half the clouds on two streams: while one chain's launch ramps up or drains, the other's
+// waves hold the vector pipes — what a persistent per-cloud kernel would give, without a flag hand-off and without anything that
+// could wait for a workgroup the dispatcher has not placed.  Per cloud the arithmetic is that of one chain
+// (the halves may run other rows-per-lane instances, which are bit-identical per row): match-free cost within the partials'
+// regrouping (2e-6, as between instances), gradients identical.  Measured at B = 64, N = 2048: 1.370 -> 1.280 ms per call.
+// The second stream is the library's own, one per device, created on first use (non-blocking, high priority: its own hardware
+// queue).  HP_EMD_CHAINS=1 / hp_emd_set_chains(1): one chain (rounds 1-4).
+
+hipStream_t second_chain_stream() {
+    static std::mutex mu;
+    static std::map<int, hipStream_t> streams;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = streams.find(dev);
+    if (it != streams.end()) return it->second;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // (numerically lowest = highest priority)
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) != hipSuccess) {
+        (void)hipGetLastError();
+        s = nullptr;
+    }
+    streams[dev] = s;
+    return s;
+}
+
+int emd_forward_impl(int b, int n, int m, const float* xyz1, const float* xyz2, float* temp, float* ws, float* partials,
+                     float* cost, float* grad1, float* grad2, float acc_scale, hipStream_t stream, hipStream_t after) {
+    HP_CHECK_ARG(b >= 0 && n > 0 && m > 0);
+    if (b == 0) return 0;
+    HP_CHECK_ARG(xyz1 && xyz2 && temp && ws && partials && cost && b <= 65535);
+    // two chains only where a half still fills the chip (>= 2 waves per SIMD at one row per lane) and a capture is not in
+    // progress on the caller's stream (a captured call stays on the stream it was captured on)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &cap);
+    const int h = b / 2;
+    const bool split = g_chains.load(std::memory_order_relaxed) == 2 && cap == hipStreamCaptureStatusNone &&
+                       (long)h * ((std::min(n, m) + kRowsPerWg - 1) / kRowsPerWg) * (kThreads / 64) >= 2048;
+    hipStream_t s2 = split ? second_chain_stream() : nullptr;
+    if (!s2) return emd_forward_chain(b, n, m, xyz1, xyz2, temp, ws, partials, cost, grad1, grad2, acc_scale, stream, after);
+    const WsLayout L = ws_layout(n, m);
+    const long per_part = (std::max(n, m) + kRowsPerWg - 1) / kRowsPerWg;      // hp_emd_partials_floats per cloud
+    int rc = hp_order_streams(stream, s2);                                       // the inputs are ready on `stream`
+    if (rc) return rc;
+    rc = emd_forward_chain(h, n, m, xyz1, xyz2, temp, ws, partials, cost, grad1, grad2, acc_scale, stream, after);
+    if (rc) return rc;
+    rc = emd_forward_chain(b - h, n, m, xyz1 + (long)h * n * 3, xyz2 + (long)h * m * 3, temp + (long)h * (n + m) * 2, ws + (long)h * L.per_cloud,
+                           partials + (long)h * per_part, cost + h, grad1 ? grad1 + (long)h * n * 3 : nullptr,
+                           grad2 ? grad2 + (long)h * m * 3 : nullptr, acc_scale, s2, (after && after != stream) ? after : nullptr);
+    if (rc) return rc;
+    return hp_order_streams(s2, stream);
 }
 
 }  // namespace

@@ -13,7 +13,7 @@
  *      approxmatch.cu:334-337; its nndistance launchers check nothing, nndistance.cu:131-160).
  * Layouts are the reference's: point sets (b, n, 3) fp32 contiguous, indices int32.
  *
- * TEST HOOKS.  hp_emd_set_rows_per_lane, hp_emd_set_final_derive, hp_encoder_backward_set_fused, hp_encoder_backward_set_chain_f16, hp_hypernet_set_heads_stream, hp_conv_split_set, hp_skinny_set_enabled,
+ * TEST HOOKS.  hp_emd_set_rows_per_lane, hp_emd_set_final_derive, hp_emd_set_chains, hp_encoder_backward_set_fused, hp_encoder_backward_set_chain_f16, hp_hypernet_set_heads_stream, hp_conv_split_set, hp_skinny_set_enabled,
  * hp_target_fused_set_f16 (and hp_conv_presplit_set below) flip PROCESS-WIDE switches that select between implementations of
  * the same result; they exist so that the parity tests can hold every implementation against the oracle in one process.  They
  * are plain globals: not thread-safe, not per-stream, not meant to be called while another host thread is inside the library.
@@ -69,6 +69,15 @@ int hp_emd_set_rows_per_lane(int rows1, int rows2, int grad2);
  * setting.  The level sweeps and the `match` tensor hp_approxmatch / hp_approxmatch_ws return are never derived. */
 /* [test hook: process-wide, not thread-safe — see the header comment] */
 int hp_emd_set_final_derive(int on);
+/* hp_emd_forward / hp_emd_forward_acc run the clouds as TWO chains of launches — the first half of the batch on the caller's
+ * stream, the second half on a stream the library owns (one per device, created on first use), ordered behind everything the
+ * caller's stream held at the call and joined back into it before the call returns control of the stream: to the caller it is one
+ * asynchronous call on `stream`, as before.  While one chain's launch ramps up or drains, the other's waves hold the vector pipes
+ * (B = 64, N = 2048: 1.37 -> 1.28 ms).  Used when each half still fills the chip and `stream` is not being captured; per cloud the
+ * results are those of one chain (gradients identical, cost within the 2e-6 of the partial sums' grouping).  2 (default;
+ * environment HP_EMD_CHAINS=1 at load time): two chains; 1: one.  Returns the previous setting. */
+/* [test hook: process-wide, not thread-safe — see the header comment] */
+int hp_emd_set_chains(int chains);
 
 /* Match-free EMD (what match_cost.py:9-46 computes through ApproxMatch + MatchCost + MatchCostGrad, without ever
  * writing the (b,m,n) match tensor): cost (b,) plus whichever of grad1 = d cost/d xyz1, grad2 = d cost/d xyz2 the

@@ -413,6 +413,33 @@ def test_emd_rows_per_lane_instances_agree_bit_for_bit(backend, rows_per_lane, b
                     assert torch.equal(x, y), (r1, r2, g2, i)
 
 
+@pytest.mark.parametrize("b,n,m", [(64, 2048, 2048), (32, 2048, 2048), (33, 1500, 2048), (130, 512, 640)])
+def test_emd_two_chains_equal_one_chain(b, n, m):
+    """hp_emd_forward runs a batch that fills the chip twice over as two chains of launches on two streams (emd.hip,
+    emd_forward_impl).  Clouds are independent and every row sees the same operations in the same order whatever instance its
+    half runs: gradients IDENTICAL to the one-chain call's, cost within 2e-6 (the grouping of its partial sums) — with both
+    gradients, with the training call's (grad1 = NULL) and at an odd batch (the halves differ in size)."""
+    from hyperpocket_amd._lib import load_library
+    lib = load_library()
+    a, c = _clouds(b + n, b, n, m)
+    prev = lib.hp_emd_set_chains(1)
+    try:
+        one = _emd_forward(a, c, True, True)
+        one_b = _emd_forward(a, c, False, True)
+        lib.hp_emd_set_chains(2)
+        for _ in range(2):      # (twice: the second call re-uses the library's stream and its ordering events)
+            two = _emd_forward(a, c, True, True)
+            two_b = _emd_forward(a, c, False, True)
+            for x, y in ((one, two), (one_b, two_b)):
+                np.testing.assert_allclose(y[0].cpu().numpy(), x[0].cpu().numpy(), rtol=2e-6)
+                for gx, gy in zip(x[1:], y[1:]):
+                    assert (gx is None) == (gy is None)
+                    if gx is not None:
+                        assert torch.equal(gx, gy)
+    finally:
+        lib.hp_emd_set_chains(prev)
+
+
 def test_emd_final_sweep_derived_exponentials_vs_all_nine_from_hardware(oracle_lib):
     """The match-free cost / gradient sweep forms four of its nine per-level exponentials as the fourth power of their
     neighbour's (emd.hip match_entry2<., DERIVE>; default on).  Against the same sweep with all nine from v_exp_f32, over the
