@@ -657,54 +657,82 @@ __global__ __launch_bounds__(256) void emd_cost_finish_kernel(const float* __res
 // and the cost/gradient sweeps re-evaluate from the final records — and remainL's final value in `temp`: the API path
 // (hp_approxmatch_ws) returns that, the match-free training path (hp_emd_forward) has no reader for it and skips the
 // launch (one of 28 exponential sweeps, 55 us at B=64, N=2048).
+// The level sweeps of `b` clouds as a sequence of launches on one stream, one step at a time: step 0 = the record set-up,
+// step 1 = phase 1 of level 0, then per level phase 2 and the merged phase-3 / next-phase-1 launch.  Stepwise so that two
+// chains (emd_forward_impl) can be ENQUEUED alternately: the host then feeds both streams at the same pace and the chains
+// run side by side from the first launch to the last (enqueued one after the other, the second chain trailed the first by
+// the host's ~0.2 ms of launch calls and ran its last sweeps alone on a half-empty chip).
+struct LevelChain {
+    Ctx c;
+    int b;
+    hipStream_t stream;
+    bool final_remainL;
+    float multiL, multiR;
+    int rows1_r, rows2_r;
+    dim3 ginit, g1[3], g2[3];      // grids at 1, 2, 4 rows per lane
+
+    LevelChain(int b_, int n, int m, const float* xyz1, const float* xyz2, float* temp, float* ws, hipStream_t st, bool frl)
+        : b(b_), stream(st), final_remainL(frl) {
+        const WsLayout L = ws_layout(n, m);
+        c = Ctx{n, m, L.NP, L.MP, xyz1, xyz2, temp, ws, L.plp, L.prp, L.rr, L.flp, L.frp, L.per_cloud};
+        if (n >= m) {
+            multiL = 1;
+            multiR = (float)(n / m);  // integer division (approxmatch.cu:37-43)
+        } else {
+            multiL = (float)(m / n);
+            multiR = 1;
+        }
+        for (int i = 0; i < 3; ++i) {
+            const int r = 1 << i;
+            g1[i] = dim3((n + r * kRowsPerWg - 1) / (r * kRowsPerWg), b);
+            g2[i] = dim3((m + r * kRowsPerWg - 1) / (r * kRowsPerWg), b);
+        }
+        ginit = dim3(((L.NP + L.MP + 2 * kSpare) / 2 + 255) / 256, b);
+        // rows per lane: the most that still leaves >= 2 waves per SIMD on the chip (measured at B=64, N=2048 on the whole
+        // step: phase 1/3 kernel best at 2 — 4 costs occupancy it needs —, phase 2 at 4: -0.10 ms together; tools/emd_rows_sweep.sh).
+        // hp_emd_set_rows_per_lane (or HP_EMD_ROWS1_R / HP_EMD_ROWS2_R at load time) overrides: every instance is a
+        // per-row-identical evaluation (tests/test_structural_losses_gpu.py compares them bit for bit and with the oracle).
+        auto pick = [&](int rows, int cap) {
+            for (int r = cap; r > 1; r >>= 1)
+                if ((long)b * ((rows + r * kRowsPerWg - 1) / (r * kRowsPerWg)) * (kThreads / 64) >= 2048) return r;
+            return 1;
+        };
+        const int f1 = g_rows1.load(std::memory_order_relaxed), f2 = g_rows2.load(std::memory_order_relaxed);
+        rows1_r = f1 ? f1 : pick(n, 2);
+        rows2_r = f2 ? f2 : pick(m, 4);
+    }
+
+    template <bool D3, bool D1>
+    void rows1(int lev1, float l2e3, float l2e1) const {
+        if (rows1_r == 4) hipLaunchKernelGGL((emd_rows1_kernel<D3, D1, 4>), g1[2], dim3(kThreads), 0, stream, c, lev1, l2e3, l2e1);
+        else if (rows1_r == 2) hipLaunchKernelGGL((emd_rows1_kernel<D3, D1, 2>), g1[1], dim3(kThreads), 0, stream, c, lev1, l2e3, l2e1);
+        else hipLaunchKernelGGL((emd_rows1_kernel<D3, D1, 1>), g1[0], dim3(kThreads), 0, stream, c, lev1, l2e3, l2e1);
+    }
+    void rows2(int lev) const {
+        if (rows2_r == 4) hipLaunchKernelGGL(emd_rows2_kernel<4>, g2[2], dim3(kThreads), 0, stream, c, lev, level_l2e(lev));
+        else if (rows2_r == 2) hipLaunchKernelGGL(emd_rows2_kernel<2>, g2[1], dim3(kThreads), 0, stream, c, lev, level_l2e(lev));
+        else hipLaunchKernelGGL(emd_rows2_kernel<1>, g2[0], dim3(kThreads), 0, stream, c, lev, level_l2e(lev));
+    }
+    static constexpr int kSteps = 2 + 2 * kLevels;
+    void step(int s) const {
+        if (s == 0) {
+            hipLaunchKernelGGL(emd_init_kernel, ginit, dim3(256), 0, stream, c, multiL, multiR);
+        } else if (s == 1) {
+            rows1<false, true>(0, 0.f, level_l2e(0));
+        } else {
+            const int lev = (s - 2) >> 1;
+            if (((s - 2) & 1) == 0) rows2(lev);
+            else if (lev + 1 < kLevels) rows1<true, true>(lev + 1, level_l2e(lev), level_l2e(lev + 1));
+            else if (final_remainL) rows1<true, false>(lev, level_l2e(lev), 0.f);
+        }
+    }
+};
+
 int run_levels(int b, int n, int m, const float* xyz1, const float* xyz2, float* temp, float* ws, Ctx* out, hipStream_t stream,
                bool final_remainL) {
-    const WsLayout L = ws_layout(n, m);
-    Ctx c{n, m, L.NP, L.MP, xyz1, xyz2, temp, ws, L.plp, L.prp, L.rr, L.flp, L.frp, L.per_cloud};
-    float multiL, multiR;
-    if (n >= m) {
-        multiL = 1;
-        multiR = (float)(n / m);  // integer division (approxmatch.cu:37-43)
-    } else {
-        multiL = (float)(m / n);
-        multiR = 1;
-    }
-    const dim3 g1((n + kRowsPerWg - 1) / kRowsPerWg, b), g2((m + kRowsPerWg - 1) / kRowsPerWg, b);
-    const dim3 g2r((m + 2 * kRowsPerWg - 1) / (2 * kRowsPerWg), b), g2q((m + 4 * kRowsPerWg - 1) / (4 * kRowsPerWg), b);
-    const dim3 g1r((n + 2 * kRowsPerWg - 1) / (2 * kRowsPerWg), b), g1q((n + 4 * kRowsPerWg - 1) / (4 * kRowsPerWg), b);
-    // rows per lane: the most that still leaves >= 2 waves per SIMD on the chip (measured at B=64, N=2048 on the whole
-    // step: phase 1/3 kernel best at 2 — 4 costs occupancy it needs —, phase 2 at 4: -0.10 ms together; tools/emd_rows_sweep.sh).
-    // hp_emd_set_rows_per_lane (or HP_EMD_ROWS1_R / HP_EMD_ROWS2_R at load time) overrides: every instance is a
-    // per-row-identical evaluation (tests/test_structural_losses_gpu.py compares them bit for bit and with the oracle).
-    auto pick = [&](int rows, int cap) {
-        for (int r = cap; r > 1; r >>= 1)
-            if ((long)b * ((rows + r * kRowsPerWg - 1) / (r * kRowsPerWg)) * (kThreads / 64) >= 2048) return r;
-        return 1;
-    };
-    const int f1 = g_rows1.load(std::memory_order_relaxed), f2 = g_rows2.load(std::memory_order_relaxed);
-    const int rows1_r = f1 ? f1 : pick(n, 2), rows2_r = f2 ? f2 : pick(m, 4);
-    hipLaunchKernelGGL(emd_init_kernel, dim3(((L.NP + L.MP + 2 * kSpare) / 2 + 255) / 256, b), dim3(256), 0, stream, c, multiL, multiR);
-#define HP_ROWS1(D3, D1, ...)                                                                                          \
-    do {                                                                                                                \
-        if (rows1_r == 4) hipLaunchKernelGGL((emd_rows1_kernel<D3, D1, 4>), g1q, dim3(kThreads), 0, stream, __VA_ARGS__); \
-        else if (rows1_r == 2) hipLaunchKernelGGL((emd_rows1_kernel<D3, D1, 2>), g1r, dim3(kThreads), 0, stream, __VA_ARGS__); \
-        else hipLaunchKernelGGL((emd_rows1_kernel<D3, D1, 1>), g1, dim3(kThreads), 0, stream, __VA_ARGS__);              \
-    } while (0)
-    HP_ROWS1(false, true, c, 0, 0.f, level_l2e(0));
-    for (int lev = 0; lev < kLevels; ++lev) {
-        if (rows2_r == 4)
-            hipLaunchKernelGGL(emd_rows2_kernel<4>, g2q, dim3(kThreads), 0, stream, c, lev, level_l2e(lev));
-        else if (rows2_r == 2)
-            hipLaunchKernelGGL(emd_rows2_kernel<2>, g2r, dim3(kThreads), 0, stream, c, lev, level_l2e(lev));
-        else
-            hipLaunchKernelGGL(emd_rows2_kernel<1>, g2, dim3(kThreads), 0, stream, c, lev, level_l2e(lev));
-        if (lev + 1 < kLevels)
-            HP_ROWS1(true, true, c, lev + 1, level_l2e(lev), level_l2e(lev + 1));
-        else if (final_remainL)
-            HP_ROWS1(true, false, c, lev, level_l2e(lev), 0.f);
-    }
-#undef HP_ROWS1
-    *out = c;
+    const LevelChain ch(b, n, m, xyz1, xyz2, temp, ws, stream, final_remainL);
+    for (int s = 0; s < LevelChain::kSteps; ++s) ch.step(s);
+    *out = ch.c;
     return (int)hipGetLastError();
 }
 
@@ -890,11 +918,20 @@ HP_API int hp_emd_forward_acc(int b, int n, int m, const float* xyz1, const floa
 
 namespace {
 // ONE chain: the 18 level sweeps + the final sweep of `b` clouds, launch behind launch on `stream`.
+int emd_final_sweep(Ctx c, int b, float* partials, float* cost, float* grad1, float* grad2, float acc_scale, hipStream_t stream,
+                    hipStream_t after);
 int emd_forward_chain(int b, int n, int m, const float* xyz1, const float* xyz2, float* temp, float* ws, float* partials,
                       float* cost, float* grad1, float* grad2, float acc_scale, hipStream_t stream, hipStream_t after) {
     Ctx c;
     int rc = run_levels(b, n, m, xyz1, xyz2, temp, ws, &c, stream, false);   // temp is scratch here
     if (rc) return rc;
+    return emd_final_sweep(c, b, partials, cost, grad1, grad2, acc_scale, stream, after);
+}
+// the cost / gradient sweep(s) of one chain behind its level sweeps
+int emd_final_sweep(Ctx c, int b, float* partials, float* cost, float* grad1, float* grad2, float acc_scale, hipStream_t stream,
+                    hipStream_t after) {
+    const int n = c.n, m = c.m;
+    int rc = 0;
     c.acc_scale = acc_scale;
     if (after && after != stream) {   // the accumulated-into gradient was written on `after`: order the sweep behind it
         rc = hp_order_streams(after, stream);
@@ -975,16 +1012,23 @@ int emd_forward_impl(int b, int n, int m, const float* xyz1, const float* xyz2, 
     hipStream_t s2 = split ? second_chain_stream() : nullptr;
     if (!s2) return emd_forward_chain(b, n, m, xyz1, xyz2, temp, ws, partials, cost, grad1, grad2, acc_scale, stream, after);
     const WsLayout L = ws_layout(n, m);
-    const long per_part = (std::max(n, m) + kRowsPerWg - 1) / kRowsPerWg;      // hp_emd_partials_floats per cloud
     int rc = hp_order_streams(stream, s2);                                       // the inputs are ready on `stream`
     if (rc) return rc;
-    rc = emd_forward_chain(h, n, m, xyz1, xyz2, temp, ws, partials, cost, grad1, grad2, acc_scale, stream, after);
+    const LevelChain c0(h, n, m, xyz1, xyz2, temp, ws, stream, false);
+    const LevelChain c1(b - h, n, m, xyz1 + (long)h * n * 3, xyz2 + (long)h * m * 3, temp + (long)h * (n + m) * 2, ws + (long)h * L.per_cloud,
+                        s2, false);
+    for (int st = 0; st < LevelChain::kSteps; ++st) {      // alternately: both streams are fed at the same pace
+        c0.step(st);
+        c1.step(st);
+    }
+    rc = (int)hipGetLastError();
     if (rc) return rc;
-    rc = emd_forward_chain(b - h, n, m, xyz1 + (long)h * n * 3, xyz2 + (long)h * m * 3, temp + (long)h * (n + m) * 2, ws + (long)h * L.per_cloud,
-                           partials + (long)h * per_part, cost + h, grad1 ? grad1 + (long)h * n * 3 : nullptr,
-                           grad2 ? grad2 + (long)h * m * 3 : nullptr, acc_scale, s2, (after && after != stream) ? after : nullptr);
+    // the final sweep is ONE launch over all clouds again, behind both chains: it is a single long launch (nothing follows it that
+    // could cover its tail), and as two half-size launches the second ran its last ~110 us alone on a half-empty chip
+    // (173 + 284 us in the trace against 288 for the whole batch)
+    rc = hp_order_streams(s2, stream);
     if (rc) return rc;
-    return hp_order_streams(s2, stream);
+    return emd_final_sweep(c0.c, b, partials, cost, grad1, grad2, acc_scale, stream, after);
 }
 
 }  // namespace
