@@ -408,8 +408,8 @@ def _pmc_profile(suffix):
 
 
 def roofline_emd(batch, n):
-    """The DOMINANT kernel family of the Chamfer+EMD step: the EMD sweeps of one hp_emd_forward call (emd_rows1 x9, emd_rows2 x9,
-    emd_grad2 — 47 % of the step's kernel time in profiles/).  Neither HBM- nor MFMA-bound: the match-free design
+    """The DOMINANT kernel family of the Chamfer+EMD step: the EMD sweeps of one hp_emd_forward call (emd_rows1 x9, emd_rows2 x9 — per
+    chain of half the clouds since round 5 —, emd_grad2: about half of the step's kernel time in profiles/).  Neither HBM- nor MFMA-bound: the match-free design
     removed the 20.4 GB/call of `match` traffic SURVEY 8(d) prices (measured: ~1 GB/call), and there is no matrix work; what
     bounds it is the quarter-rate v_exp_f32.  SURVEY 8(d) fixes the ALGORITHMIC work at 27 exponentials per point pair (three
     phases x nine levels, approxmatch.cu:86,131,185), so
@@ -440,7 +440,8 @@ def roofline_emd(batch, n):
     pairs = float(batch) * n * n
     achieved = 27.0 * pairs / (ms * 1e-3) / 1e12
     out = {"bound": "valu-exp",
-           "kernel": "hp_emd_forward = emd_rows1_kernel x9 + emd_rows2_kernel x9 + emd_grad2_kernel "
+           "kernel": "hp_emd_forward = 9 x (emd_rows1_kernel + emd_rows2_kernel) level sweeps, since round 5 as two chains of half the clouds on "
+                     "two streams, + one emd_grad2_kernel over all clouds "
                      f"(B={batch}, n=m={n}, cost + d cost/d xyz2; inputs U(-0.5,0.5)^3 — the launches' duration does not depend on the data)",
            "achieved": round(achieved, 3), "peak": round(PEAK_TEXP_PER_S, 2), "unit": "Texp/s",
            "frac": round(achieved / PEAK_TEXP_PER_S, 4),
