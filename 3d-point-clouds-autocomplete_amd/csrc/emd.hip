@@ -97,6 +97,8 @@ inline int env_rows(const char* name) {
     const int v = e ? atoi(e) : 0;
     return (v == 1 || v == 2 || v == 4) ? v : 0;
 }
+std::mutex g_s2_mu;                            // the library's second-chain stream per device (emd_forward_impl)
+std::map<int, hipStream_t> g_s2_streams;
 // hp_emd_forward* as two chains of half the clouds on two streams (2) or one chain (1): emd_forward_impl
 std::atomic<int> g_chains{[] { const char* e = getenv("HP_EMD_CHAINS"); const int v = e ? atoi(e) : 2; return v == 1 ? 1 : 2; }()};
 // the final cost / gradient sweep with derived exponentials (match_entry2<.., DERIVE>): on unless HP_EMD_FINAL_DERIVE=0
@@ -979,8 +981,8 @@ int emd_final_sweep(Ctx c, int b, float* partials, float* cost, float* grad1, fl
 // queue).  HP_EMD_CHAINS=1 / hp_emd_set_chains(1): one chain (rounds 1-4).
 
 hipStream_t second_chain_stream() {
-    static std::mutex mu;
-    static std::map<int, hipStream_t> streams;
+    std::mutex& mu = g_s2_mu;
+    std::map<int, hipStream_t>& streams = g_s2_streams;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
