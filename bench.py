@@ -762,12 +762,17 @@ def main():
                 # inside this process (rounds 3-4) measured that accident, not the exchange (0.09 ... 2.4 ms with the same binary).
                 try:
                     torch.cuda.synchronize()
-                    env = dict(os.environ, HP_BENCH_FORCE_EXCHANGE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541",
+                    def free_port():
+                        with socket.socket() as sk:
+                            sk.bind(("127.0.0.1", 0))
+                            return str(sk.getsockname()[1])
+                    env = dict(os.environ, HP_BENCH_FORCE_EXCHANGE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=free_port(),
                                HSA_ENABLE_IPC_MODE_LEGACY="0")
                     cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--batch", str(args.batch),
                            "--points", str(args.points), "--no-extras", "--no-cpu-baseline"] + (["--no-emd"] if args.no_emd else [])
                     legs = []
                     for _ in range(2):      # (two children, the faster one: the first pays the box's cold caches)
+                        env["MASTER_PORT"] = free_port()
                         p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
                         rec = [json.loads(ln) for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
                         legs.append(rec[-1]["ms_per_step"])
