@@ -951,20 +951,24 @@ def _full_model_vs_reference_golden(name, ref, oracle_lib):
     # (equally valid) fp32 summation order picks the other one and that channel's gradient is routed elsewhere — the
     # reference's own fp32 gradient then differs from the exact one by O(1e-2) (measured: tools/debug_grads.py).
     # For encoder parameters only, agreement with the oracle evaluated in fp64 is accepted instead.
+    # The trained fixture's captured step was drawn with a margin at every discrete decision (make_golden.py): there the bar is
+    # 1e-4 of each tensor's scale against the reference's own fp32 gradient, for EVERY tensor, no fallback (measured: < 1e-4 in
+    # both arithmetics).
     truth = None
     via_f64 = []
+    gtol = 1e-4 if trained else 5e-4
     for k, p in model.named_parameters():
         key = k.replace(".", "__")
         if "gnone__" + key in g:
             assert p.grad is None, k
             continue
         gn = g["gnorm__" + key]
-        ok = abs(p.grad.double().norm().item() - gn[0]) <= 5e-4 * gn[0] + 1e-12
+        ok = abs(p.grad.double().norm().item() - gn[0]) <= gtol * gn[0] + 1e-12
         try:
             if "gfull__" + key in g:
-                grad_close(p.grad.flatten(), g["gfull__" + key], tol=5e-4)
+                grad_close(p.grad.flatten(), g["gfull__" + key], tol=gtol)
             else:
-                grad_close(p.grad.flatten()[torch.from_numpy(g["gidx__" + key]).cuda()], g["gsamp__" + key], tol=5e-4)
+                grad_close(p.grad.flatten()[torch.from_numpy(g["gidx__" + key]).cuda()], g["gsamp__" + key], tol=gtol)
         except AssertionError:
             ok = False
         if not ok:
@@ -973,7 +977,7 @@ def _full_model_vs_reference_golden(name, ref, oracle_lib):
                 truth = _oracle_grads_f64(ref, g)
             grad_close(p.grad, truth[k], tol=2e-5)
             via_f64.append(k)
-    assert len(via_f64) <= 16, via_f64
+    assert len(via_f64) <= (0 if trained else 16), via_f64
 
 
 def _oracle_grads_f64(ref, g):
