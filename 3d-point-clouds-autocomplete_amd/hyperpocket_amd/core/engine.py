@@ -237,6 +237,9 @@ class TrainEngine:
         import os as _os
         self._join_early = _os.environ.get("HP_HEADS_JOIN_AT_STEP_END", "0") == "1"
         self._loss_side_stream = _os.environ.get("HP_LOSS_SIDE_STREAM", "1") != "0"
+        self._predraw_on = _os.environ.get("HP_PREDRAW", "1") != "0"
+        self._next_eps = self._next_points = None      # pre-drawn for the next step (step / _predraw)
+        self._draws_eps = self._draws_points = False   # the caller has left a draw to the engine at least once
         # The model only holds WEAK references to its engine (a dropped engine must not stay pinned — with its four flat
         # 173 MB buffers — by the model's hooks), and a new engine on the same model takes the hooks over.
         prev = model.__dict__.get("_engine_ref")
@@ -312,6 +315,18 @@ class TrainEngine:
         model._after_encoder_tails = self.fused if (self.fused is not None and self.fused.stream is not None) else None
         if self.fused is not None:
             self.fused.check()     # (a pass left over from a failed step must not be cleared silently)
+        # The step's own random draws — eps of the VAE encoder, the decoder's input points — depend on nothing: the PREVIOUS step
+        # drew them on the side stream, beside its EMD sweeps (_predraw), so that the two small launches (4 + 8 us with their
+        # gaps) are not on the compute stream between the optimiser and the first conv launch / in front of the decoder.  The
+        # n-th draw of each sequence is the n-th value either way; draws a caller injects (tests) leave the pre-drawn ones for
+        # the next step that does not.
+        want = (gt.size(0), gt.size(1), epoch)
+        self._draws_eps, self._draws_points = self._draws_eps or eps_noise is None, self._draws_points or points is None
+        if eps_noise is None and self._next_eps is not None and self._next_eps[0] == want[0]:
+            eps_noise, self._next_eps = self._next_eps[1], None
+        if points is None and self._next_points is not None and self._next_points[0] == want:
+            points, self._next_points = self._next_points[1], None
+        self._predraw_for = (want, eps_noise is not None, points is not None)
         # forward() transposes its inputs in place: hand it views it may mutate
         rec, logvar, mu = model(existing.view(existing.shape), None if missing is None else missing.view(missing.shape),
                                 list(gt.shape), epoch, device, points=points, eps=eps_noise)
@@ -425,6 +440,8 @@ class TrainEngine:
                 call("hp_kld_forward", n_el, batch, lv_c, mu_c, kld, st)
                 call("hp_kld_backward", n_el, batch, lv_c, mu_c, one, g_lv, g_mu, st)
             del dist1, dist2, idx1, idx2, part
+            if side is not None and self._predraw_on:
+                self._predraw(dev)      # next step's eps and decoder points, on this stream (no dependency, nothing waits for them)
         cost = None
         c_emd = 0.0
         if self.emd_coef:
@@ -453,6 +470,21 @@ class TrainEngine:
             roots += [logvar, mu]
             grads += [g_lv.view_as(logvar), g_mu.view_as(mu)]
         return roots, grads, out
+
+    def _predraw(self, dev):
+        """Next step's random draws (called on the side stream).  Only what this step did NOT get injected, and only for the
+        shapes of this step (another batch size or epoch next time: the pre-drawn tensors are ignored and drawn again then —
+        the device sampler's counter has moved, which shifts its sequence but not its law)."""
+        model = self.model
+        (B, N, epoch), eps_given, pts_given = self._predraw_for
+        auto_eps = getattr(self, "_auto_eps", None)
+        if auto_eps is None:      # does this model draw eps itself in training? (HyperPocket / HyperCloud: the VAE encoder)
+            auto_eps = self._auto_eps = bool(model.mode.vae_input)
+        if auto_eps and self._next_eps is None and (self._draws_eps or not eps_given):
+            enc = model.random_encoder
+            self._next_eps = (B, torch.randn((B, enc.output_size), dtype=torch.float32, device=dev))
+        if model.point_sampler == "device" and self._next_points is None and (self._draws_points or not pts_given):
+            self._next_points = ((B, N, epoch), model._draw_points(epoch, B, N, dev))
 
     def _adam(self, bucket):
         self._adam_range(*self.flat.buckets[bucket])
