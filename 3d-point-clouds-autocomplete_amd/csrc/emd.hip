@@ -24,6 +24,11 @@
 //     fma chain, products entering the running sums through an fma, ascending candidate order in the
 //     accumulators): the C oracle's `contract` variant 3.
 //   * padding records carry zero weights and contribute exact zeros.
+//   * round 5: (a) the match-free cost / gradient sweep derives four of its nine per-level exponentials as fourth powers of their
+//     neighbours (the levels are exact powers of 4 apart; only there — nothing is downstream of those values; match_entry2);
+//     (b) the clouds are independent but a launch is not: every one of the 19 dependent launches pays ramp, prologue, epilogue
+//     and tail with the whole chip in lockstep, so hp_emd_forward* runs the level sweeps as TWO chains of half the clouds on two
+//     streams, enqueued alternately, and one chain's waves cover the other's launch boundaries (LevelChain, emd_forward_impl).
 #include "hp_common.h"
 #include <algorithm>
 #include <atomic>
