@@ -1033,9 +1033,17 @@ int emd_forward_impl(int b, int n, int m, const float* xyz1, const float* xyz2, 
     // the final sweep is ONE launch over all clouds again, behind both chains: it is a single long launch (nothing follows it that
     // could cover its tail), and as two half-size launches the second ran its last ~110 us alone on a half-empty chip
     // (173 + 284 us in the trace against 288 for the whole batch)
+    // ... and behind `after` (the stream that wrote the gradient the sweep accumulates into).  Every wait costs the waiting stream a
+    // bubble of several microseconds even when the event has long fired, so the caller's stream gets ONE: `after` is joined into
+    // the second chain's stream first (nothing is queued there behind its chain), and that stream into the caller's.
+    const bool ext = after && after != stream && acc_scale != 0.f;
+    if (ext) {
+        rc = hp_order_streams(after, s2);
+        if (rc) return rc;
+    }
     rc = hp_order_streams(s2, stream);
     if (rc) return rc;
-    return emd_final_sweep(c0.c, b, partials, cost, grad1, grad2, acc_scale, stream, after);
+    return emd_final_sweep(c0.c, b, partials, cost, grad1, grad2, acc_scale, stream, ext ? nullptr : after);
 }
 
 }  // namespace
