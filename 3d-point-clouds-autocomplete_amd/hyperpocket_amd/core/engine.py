@@ -322,9 +322,13 @@ class TrainEngine:
         # the next step that does not.
         want = (gt.size(0), gt.size(1), epoch)
         self._draws_eps, self._draws_points = self._draws_eps or eps_noise is None, self._draws_points or points is None
-        if eps_noise is None and self._next_eps is not None and self._next_eps[0] == want[0]:
+        if self._next_eps is not None and self._next_eps[0] != want[0]:
+            self._next_eps = None              # drawn for another batch size: drop it (it would block every later pre-draw)
+        if self._next_points is not None and self._next_points[0] != want:
+            self._next_points = None           # ... another shape or epoch (the hollow's radius follows the epoch)
+        if eps_noise is None and self._next_eps is not None:
             eps_noise, self._next_eps = self._next_eps[1], None
-        if points is None and self._next_points is not None and self._next_points[0] == want:
+        if points is None and self._next_points is not None:
             points, self._next_points = self._next_points[1], None
         self._predraw_for = (want, eps_noise is not None, points is not None)
         # forward() transposes its inputs in place: hand it views it may mutate

