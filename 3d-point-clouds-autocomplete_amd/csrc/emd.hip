@@ -81,8 +81,13 @@ inline int pad_up(int x) { return (x + 2 * kStage * kParts - 1) / (2 * kStage * 
 //   FLP / FRP  "final" pair records (32 floats per PAIR): [x0 x1 y0 y1 z0 z1 | r(lev0)0 r(lev0)1 | ... | r(lev8)0 r(lev8)1 | 8 pad]
 struct WsLayout {
     int NP, MP;
-    long plp, prp, rr, flp, frp, per_cloud;
+    long plp, prp, rr, flp, frp, permL, permR, blkL, blkR, tileL, tileR, flag, per_cloud;
 };
+// Round 6 (ordered / culling sweeps): per set the k-d order (position -> original index, int32 in a float slot), the bounding
+// boxes of its 8-candidate blocks (SoA: [minx | miny | minz | maxx | maxy | maxz] x NP/8) and of its 64-row tiles (x NP/64), and
+// one flag block per cloud (flag[0] != 0: the records are in k-d order).
+constexpr int kBlk = 8;      // candidates per cull block = one software-pipeline stage of pair records
+constexpr int kTile = 64;    // rows per cull tile = the rows one wave owns per row slot
 inline WsLayout ws_layout(int n, int m) {
     WsLayout w;
     w.NP = pad_up(n);
@@ -92,7 +97,14 @@ inline WsLayout ws_layout(int n, int m) {
     w.rr = w.prp + (long)(w.MP + kSpare) * 4;
     w.flp = w.rr + (long)(w.MP + kSpare);
     w.frp = w.flp + (long)(w.NP + kSpare) * 16;
-    w.per_cloud = w.frp + (long)(w.MP + kSpare) * 16;
+    w.permL = w.frp + (long)(w.MP + kSpare) * 16;
+    w.permR = w.permL + w.NP;
+    w.blkL = w.permR + w.MP;
+    w.blkR = w.blkL + 6L * (w.NP / kBlk);
+    w.tileL = w.blkR + 6L * (w.MP / kBlk);
+    w.tileR = w.tileL + 6L * (w.NP / kTile);
+    w.flag = w.tileR + 6L * (w.MP / kTile);
+    w.per_cloud = w.flag + 16;
     return w;
 }
 
@@ -108,6 +120,11 @@ std::map<int, hipStream_t> g_s2_streams;
 std::atomic<int> g_chains{[] { const char* e = getenv("HP_EMD_CHAINS"); const int v = e ? atoi(e) : 2; return v == 1 ? 1 : 2; }()};
 // the final cost / gradient sweep with derived exponentials (match_entry2<.., DERIVE>): on unless HP_EMD_FINAL_DERIVE=0
 std::atomic<int> g_final_derive{[] { const char* e = getenv("HP_EMD_FINAL_DERIVE"); return (e && atoi(e) == 0) ? 0 : 1; }()};
+// hp_emd_forward*: records in k-d order and the first g_cull levels' sweeps culling (0: caller's order, no culling): hp_emd_set_cull
+constexpr int kCullDefault = 4;
+std::atomic<int> g_cull{[] { const char* e = getenv("HP_EMD_CULL"); const int v = e ? atoi(e) : kCullDefault; return v < 0 ? 0 : v > kLevels ? kLevels : v; }()};
+std::atomic<int> g_cull_rows{env_rows("HP_EMD_CULL_R")};   // rows per lane of the culling instances (0: as the plain ones)
+constexpr int kOrderMaxLog = 12;   // k-d order for sets of up to 4096 points (the order kernel's LDS: 19 bytes per point)
 std::atomic<int> g_rows1{env_rows("HP_EMD_ROWS1_R")}, g_rows2{env_rows("HP_EMD_ROWS2_R")}, g_grad2{env_rows("HP_EMD_GRAD2_R") == 4 ? 0 : env_rows("HP_EMD_GRAD2_R")};
 
 struct Ctx {
@@ -116,9 +133,21 @@ struct Ctx {
     const float* xyz2;
     float* temp;  // (b, 2(n+m)) : [remainL n | remainR m | ratioL n | ratioR m]  (reference layout, approxmatch.cu:35)
     float* ws;
-    long plp, prp, rr, flp, frp, per_cloud;
+    int plp, prp, rr, flp, frp, permL, permR, blkL, blkR, tileL, tileR, flag;   // float offsets inside a cloud's workspace (< 2^31)
+    long per_cloud;
     float acc_scale = 0.f;   // != 0: emd_grad2_kernel stores grad2[i] += acc_scale * d cost / d xyz2[i] instead of the plain gradient
 };
+inline Ctx make_ctx(int n, int m, const float* xyz1, const float* xyz2, float* temp, float* ws) {
+    const WsLayout L = ws_layout(n, m);
+    Ctx c;
+    c.n = n; c.m = m; c.NP = L.NP; c.MP = L.MP;
+    c.xyz1 = xyz1; c.xyz2 = xyz2; c.temp = temp; c.ws = ws;
+    c.plp = (int)L.plp; c.prp = (int)L.prp; c.rr = (int)L.rr; c.flp = (int)L.flp; c.frp = (int)L.frp;
+    c.permL = (int)L.permL; c.permR = (int)L.permR; c.blkL = (int)L.blkL; c.blkR = (int)L.blkR; c.tileL = (int)L.tileL; c.tileR = (int)L.tileR;
+    c.flag = (int)L.flag; c.per_cloud = L.per_cloud;
+    c.acc_scale = 0.f;
+    return c;
+}
 
 // element offsets of candidate i inside the pair-record arrays
 __device__ __forceinline__ long pair8(int i, int comp) { return (long)(i >> 1) * 8 + comp * 2 + (i & 1); }            // comp 0..3 = x,y,z,w
@@ -134,6 +163,7 @@ __global__ __launch_bounds__(256) void emd_init_kernel(Ctx c, float multiL, floa
     const float* P = c.xyz1 + (long)cloud * c.n * 3;
     const float* Q = c.xyz2 + (long)cloud * c.m * 3;
     const int NPp = (c.NP + kSpare) / 2, MPp = (c.MP + kSpare) / 2;   // pairs per set (NP, MP, kSpare are even)
+    if (blockIdx.x == 0 && threadIdx.x == 0) ws[c.flag] = 0.f;        // records in the caller's point order (see emd_order_kernel)
     for (int i = blockIdx.x * 256 + threadIdx.x; i < NPp + MPp; i += gridDim.x * 256) {
         const bool left = i < NPp;
         const int pr = left ? i : i - NPp, j0 = 2 * pr, j1 = j0 + 1;
@@ -160,6 +190,285 @@ __global__ __launch_bounds__(256) void emd_init_kernel(Ctx c, float multiL, floa
             if (ok1) remR[j1] = multiR;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Round 6: the records in HILBERT ORDER, so that the level sweeps can skip work that is exactly zero.
+// At level -16384 / -4096 / -1024 / -256 the exponential of a pair further apart than 0.080 / 0.160 / 0.321 / 0.641 underflows to
+// exactly +0 (exp2 of less than -152): its terms are exact zeros in every phase (approxmatch.cu:86-87,131-132,185-189) and a sweep
+// that leaves them out produces the same sums.  Skipping is only possible for whole (wave, pipeline stage) units, so both sets are
+// put in an order in which 64 consecutive rows and 8 consecutive candidates are spatially compact: along the Hilbert curve of a
+// 128^3 grid over the set's bounding box — consecutive cells of that curve are always neighbours, so ANY run of consecutive points
+// is compact, not only the aligned ones (Morton order jumps).  Decidable from the bounding boxes of a (64-row tile, 8-candidate
+// block) unit at the first four levels, uniform clouds: 80 / 70 / 47 / 6 % of the units (Morton 69 / 59 / 33 / 3 %; a k-d order —
+// median splits, 85 / 76 / 54 / 10 % — needs eight segment sorts instead of one and costs more than it saves:
+// tools/study/emd_cull_hilbert.py).  The algorithm is indifferent to the order of either set; a sweep in another
+// order is another summation order of the same sums (oracle on re-ordered inputs: cost within 3e-7,
+// tools/study/emd_order_sensitivity.py), and the gradient sweeps write through the permutation, so callers see their own order.
+//
+// One workgroup per (cloud, set): keys (Hilbert index | point index) are sorted by a bitonic network in LDS, three compare
+// distances per round trip (8 keys per thread in registers).  Points past the count carry the largest key and stay at the tail.
+// Then the same workgroup writes everything emd_init_kernel writes, in the new order, plus the permutation and the block / tile
+// bounding boxes.
+// ------------------------------------------------------------------------------------------------
+constexpr int kOrderThreads = 1024;   // 16 waves for the load / key / output phases; the sort network runs on the first P2/8 threads
+constexpr float kFar = 1e18f;     // an empty box: min = +kFar, max = -kFar (its gap to anything squares to 1e36 > any radius)
+
+// Hilbert index of the cell (x, y, z), `bits` bits per axis (Skilling's transpose form, then interleaved: 3 * bits bits)
+__device__ __forceinline__ uint32_t spread3(uint32_t v) {      // bit b -> bit 3b (b < 10)
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t hilbert3(uint32_t x0, uint32_t x1, uint32_t x2, int bits) {
+    const uint32_t M = 1u << (bits - 1);
+    for (uint32_t Q = M; Q > 1; Q >>= 1) {
+        const uint32_t P = Q - 1;
+        if (x0 & Q) x0 ^= P;
+        if (x1 & Q) x0 ^= P;
+        else {
+            const uint32_t t = (x0 ^ x1) & P;
+            x0 ^= t;
+            x1 ^= t;
+        }
+        if (x2 & Q) x0 ^= P;
+        else {
+            const uint32_t t = (x0 ^ x2) & P;
+            x0 ^= t;
+            x2 ^= t;
+        }
+    }
+    x1 ^= x0;
+    x2 ^= x1;
+    uint32_t t = 0;
+    for (uint32_t Q = M; Q > 1; Q >>= 1)
+        if (x2 & Q) t ^= Q - 1;
+    x0 ^= t;
+    x1 ^= t;
+    x2 ^= t;
+    return (spread3(x0) << 2) | (spread3(x1) << 1) | spread3(x2);
+}
+__device__ __forceinline__ void cmp_up(uint32_t& a, uint32_t& b) {
+    const uint32_t lo = min(a, b), hi = max(a, b);
+    a = lo;
+    b = hi;
+}
+__device__ __forceinline__ void cmp_swap(uint32_t& a, uint32_t& b, bool asc) {
+    const uint32_t lo = min(a, b), hi = max(a, b);
+    a = asc ? lo : hi;
+    b = asc ? hi : lo;
+}
+
+__global__ __launch_bounds__(kOrderThreads) void emd_order_kernel(Ctx c, float multiL, float multiR, int logpL, int logpR) {
+    extern __shared__ float smem[];
+    __shared__ float red[6][kOrderThreads / 64];
+    __shared__ float gb[6], gscale[3];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const bool left = blockIdx.x == 0;
+    const int cloud = blockIdx.y;
+    const int cnt = left ? c.n : c.m, NPx = left ? c.NP : c.MP, logp = left ? logpL : logpR, P2 = 1 << logp;
+    const float* src = (left ? c.xyz1 + (long)cloud * c.n * 3 : c.xyz2 + (long)cloud * c.m * 3);
+    float* ws = c.ws + (long)cloud * c.per_cloud;
+    float* X = smem;
+    float* Y = X + P2;
+    float* Z = Y + P2;
+    uint32_t* key = reinterpret_cast<uint32_t*>(Z + P2);
+    float* box0 = reinterpret_cast<float*>(key + P2);   // NP/8 block boxes [lo xyz | hi xyz] (the output phase)
+
+    // the points and their bounding box
+    float mn[3] = {kFar, kFar, kFar}, mx[3] = {-kFar, -kFar, -kFar};
+    for (int i = tid; i < P2; i += kOrderThreads) {
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (i < cnt) {
+            x = src[i * 3];
+            y = src[i * 3 + 1];
+            z = src[i * 3 + 2];
+            mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
+            mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
+            mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
+        }
+        X[i] = x;
+        Y[i] = y;
+        Z[i] = z;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64));
+        }
+        if (lane == 0) {
+            red[a][wid] = mn[a];
+            red[3 + a][wid] = mx[a];
+        }
+    }
+    __syncthreads();
+    const uint32_t imask = (uint32_t)P2 - 1u;
+    const int hb = (32 - logp) / 3;                           // Hilbert bits per axis (7 up to 2048 points, 6 at 4096)
+    if (tid < 3) {
+        float lo = red[tid][0], hi = red[3 + tid][0];
+        for (int w = 1; w < kOrderThreads / 64; ++w) {
+            lo = fminf(lo, red[tid][w]);
+            hi = fmaxf(hi, red[3 + tid][w]);
+        }
+        gb[tid] = lo;
+        gscale[tid] = hi > lo ? (float)(1 << hb) * 0.9999f / (hi - lo) : 0.f;
+    }
+    __syncthreads();
+    // keys: Hilbert index of the point's cell | point index; points past the count carry the largest key and stay at the tail
+    for (int i = tid; i < P2; i += kOrderThreads) {
+        uint32_t kk = 0xffffffffu;
+        if (i < cnt) {
+            const uint32_t cm = (1u << hb) - 1u;
+            const uint32_t qx = min((uint32_t)((X[i] - gb[0]) * gscale[0]), cm), qy = min((uint32_t)((Y[i] - gb[1]) * gscale[1]), cm),
+                           qz = min((uint32_t)((Z[i] - gb[2]) * gscale[2]), cm);
+            kk = (hilbert3(qx, qy, qz, hb) << logp) | (uint32_t)i;
+        }
+        key[i] = kk;
+    }
+    __syncthreads();
+    {
+        const int ls = logp;
+        // bitonic sort, ascending.  Pass 1: every thread sorts its 8 consecutive keys in registers (the merges of size 2, 4, 8), runs
+        // alternately ascending / descending; then the merges of size 16 .. P2, compare distances k/2 .. 1 taken three at a time
+        // (8 keys per thread in registers).  A descending run is an ascending run of the complemented keys.
+        for (int vt = tid; vt < P2 / 8; vt += kOrderThreads) {
+            uint4* p = reinterpret_cast<uint4*>(key + vt * 8);
+            const uint4 q0 = p[0], q1 = p[1];
+            uint32_t v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            cmp_swap(v[0], v[1], true); cmp_swap(v[2], v[3], false); cmp_swap(v[4], v[5], true); cmp_swap(v[6], v[7], false);
+            cmp_swap(v[0], v[2], true); cmp_swap(v[1], v[3], true); cmp_swap(v[4], v[6], false); cmp_swap(v[5], v[7], false);
+            cmp_swap(v[0], v[1], true); cmp_swap(v[2], v[3], true); cmp_swap(v[4], v[5], false); cmp_swap(v[6], v[7], false);
+            const bool asc = (vt & 1) == 0;
+            cmp_swap(v[0], v[4], asc); cmp_swap(v[1], v[5], asc); cmp_swap(v[2], v[6], asc); cmp_swap(v[3], v[7], asc);
+            cmp_swap(v[0], v[2], asc); cmp_swap(v[1], v[3], asc); cmp_swap(v[4], v[6], asc); cmp_swap(v[5], v[7], asc);
+            cmp_swap(v[0], v[1], asc); cmp_swap(v[2], v[3], asc); cmp_swap(v[4], v[5], asc); cmp_swap(v[6], v[7], asc);
+            p[0] = make_uint4(v[0], v[1], v[2], v[3]);
+            p[1] = make_uint4(v[4], v[5], v[6], v[7]);
+        }
+        bool wide = true;                                        // the pending writes may be read by another wave
+        for (int lk = 4; lk <= ls; ++lk) {
+            const int k = 1 << lk;
+            int rem = lk;                                        // distances left in this merge: 2^(rem-1) .. 1
+            while (rem > 0) {
+                const int gg = rem >= 3 ? 3 : rem;              // compare steps in the group (the short group last, at distance 1)
+                const int ljj = rem - gg;                       // log2 of the group's smallest distance
+                const int jj = 1 << ljj;
+                // a wave's 64 threads own 512 consecutive keys while jj <= 64: no other wave reads or writes them
+                const bool wide_now = jj > 64;
+                if (wide || wide_now) __syncthreads();
+                else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                wide = wide_now;
+                for (int vt = tid; vt < P2 / 8; vt += kOrderThreads) {
+                    const int base = ((vt >> ljj) << (ljj + 3)) | (vt & (jj - 1));
+                    const uint32_t flip = (lk == ls || (base & k) == 0) ? 0u : 0xffffffffu;
+                    uint32_t v[8];
+                    if (ljj == 0) {
+                        const uint4* p = reinterpret_cast<const uint4*>(key + base);
+                        const uint4 q0 = p[0], q1 = p[1];
+                        v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+                    } else {
+#pragma unroll
+                        for (int a = 0; a < 8; ++a) v[a] = key[base + a * jj];
+                    }
+#pragma unroll
+                    for (int a = 0; a < 8; ++a) v[a] ^= flip;
+                    if (gg == 3) {
+                        cmp_up(v[0], v[4]); cmp_up(v[1], v[5]); cmp_up(v[2], v[6]); cmp_up(v[3], v[7]);
+                    }
+                    if (gg >= 2) {
+                        cmp_up(v[0], v[2]); cmp_up(v[1], v[3]); cmp_up(v[4], v[6]); cmp_up(v[5], v[7]);
+                    }
+                    cmp_up(v[0], v[1]); cmp_up(v[2], v[3]); cmp_up(v[4], v[5]); cmp_up(v[6], v[7]);
+#pragma unroll
+                    for (int a = 0; a < 8; ++a) v[a] ^= flip;
+                    if (ljj == 0) {
+                        uint4* p = reinterpret_cast<uint4*>(key + base);
+                        p[0] = make_uint4(v[0], v[1], v[2], v[3]);
+                        p[1] = make_uint4(v[4], v[5], v[6], v[7]);
+                    } else {
+#pragma unroll
+                        for (int a = 0; a < 8; ++a) key[base + a * jj] = v[a];
+                    }
+                }
+                rem -= gg;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- outputs (what emd_init_kernel writes, in the new order) ----
+    int* perm = reinterpret_cast<int*>(ws + (left ? c.permL : c.permR));
+    for (int e = tid; e < NPx; e += kOrderThreads) perm[e] = (int)(key[e] & imask);
+    float* remL = c.temp + (long)cloud * (c.n + c.m) * 2;
+    float* remR = remL + c.n;
+    const int pairs = (NPx + kSpare) / 2;
+    for (int pr = tid; pr < pairs; pr += kOrderThreads) {
+        const int j0 = 2 * pr, j1 = j0 + 1;
+        const bool ok0 = j0 < cnt, ok1 = j1 < cnt;
+        const uint32_t i0 = ok0 ? (key[j0] & imask) : 0u, i1 = ok1 ? (key[j1] & imask) : 0u;
+        const float x0 = ok0 ? X[i0] : 0.f, y0 = ok0 ? Y[i0] : 0.f, z0 = ok0 ? Z[i0] : 0.f;
+        const float x1 = ok1 ? X[i1] : 0.f, y1 = ok1 ? Y[i1] : 0.f, z1 = ok1 ? Z[i1] : 0.f;
+        float4* p8 = reinterpret_cast<float4*>(ws + (left ? c.plp : c.prp) + (long)pr * 8);
+        float4* p32 = reinterpret_cast<float4*>(ws + (left ? c.flp : c.frp) + (long)pr * 32);
+        const float4 a = make_float4(x0, x1, y0, y1), b = make_float4(z0, z1, 0.f, 0.f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        p8[0] = a;
+        p8[1] = b;
+        p32[0] = a;
+        p32[1] = b;
+#pragma unroll
+        for (int q = 2; q < 8; ++q) p32[q] = zero;
+        if (left) {
+            if (ok0) remL[j0] = multiL;
+            if (ok1) remL[j1] = multiL;
+        } else {
+            *reinterpret_cast<float2*>(ws + c.rr + j0) = make_float2(ok0 ? multiR : 0.f, ok1 ? multiR : 0.f);
+            if (ok0) remR[j0] = multiR;
+            if (ok1) remR[j1] = multiR;
+        }
+    }
+    // bounding boxes of the 8-candidate blocks (exact, over the real points) ...
+    const int NB = NPx / kBlk, NT = NPx / kTile;
+    float* bb = ws + (left ? c.blkL : c.blkR);
+    float* lb = box0;                                  // (both box tables are free now: NB * 6 floats = their size)
+    for (int g = tid; g < NB; g += kOrderThreads) {
+        float lo[3] = {kFar, kFar, kFar}, hi[3] = {-kFar, -kFar, -kFar};
+        for (int j = g * kBlk; j < min(g * kBlk + kBlk, cnt); ++j) {
+            const uint32_t i = key[j] & imask;
+            lo[0] = fminf(lo[0], X[i]); hi[0] = fmaxf(hi[0], X[i]);
+            lo[1] = fminf(lo[1], Y[i]); hi[1] = fmaxf(hi[1], Y[i]);
+            lo[2] = fminf(lo[2], Z[i]); hi[2] = fmaxf(hi[2], Z[i]);
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            bb[q * NB + g] = lo[q];
+            bb[(3 + q) * NB + g] = hi[q];
+            lb[g * 6 + q] = lo[q];
+            lb[g * 6 + 3 + q] = hi[q];
+        }
+    }
+    __syncthreads();
+    // ... and of the 64-row tiles
+    float* tb = ws + (left ? c.tileL : c.tileR);
+    for (int t = tid; t < NT; t += kOrderThreads) {
+        float lo[3] = {kFar, kFar, kFar}, hi[3] = {-kFar, -kFar, -kFar};
+        for (int g = t * (kTile / kBlk); g < (t + 1) * (kTile / kBlk); ++g) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                lo[q] = fminf(lo[q], lb[g * 6 + q]);
+                hi[q] = fmaxf(hi[q], lb[g * 6 + 3 + q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            tb[q * NT + t] = lo[q];
+            tb[(3 + q) * NT + t] = hi[q];
+        }
+    }
+    if (left && tid == 0) ws[c.flag] = 1.f;
 }
 
 // pair record `u` (0..3) of a stage held in two x16 SGPR groups: component c (0=x,1=y,2=z,3=w) as a float2
@@ -194,11 +503,10 @@ __global__ __launch_bounds__(kThreads) void emd_rows1_kernel(Ctx c, int lev1, fl
         k[r] = (blockIdx.x * R + r) * kRowsPerWg + lrow;
         ok[r] = k[r] < c.n;
         float px = 0.f, py = 0.f, pz = 0.f, rl = 0.f;
-        if (ok[r]) {
-            const float* s = c.xyz1 + ((long)cloud * c.n + k[r]) * 3;
-            px = s[0];
-            py = s[1];
-            pz = s[2];
+        if (ok[r]) {   // the row's point from its own record (the records are in the order the sweeps run in: emd_order_kernel)
+            px = ws[c.plp + pair8(k[r], 0)];
+            py = ws[c.plp + pair8(k[r], 1)];
+            pz = ws[c.plp + pair8(k[r], 2)];
             if (DO3) rl = ratioL[k[r]];
         }
         px2[r] = splat(px);
@@ -310,10 +618,9 @@ __global__ __launch_bounds__(kThreads) void emd_rows2_kernel(Ctx c, int lev, flo
         ok[r] = l[r] < c.m;
         float qx = 0.f, qy = 0.f, qz = 0.f;
         if (ok[r]) {
-            const float* s = c.xyz2 + ((long)cloud * c.m + l[r]) * 3;
-            qx = s[0];
-            qy = s[1];
-            qz = s[2];
+            qx = ws[c.prp + pair8(l[r], 0)];
+            qy = ws[c.prp + pair8(l[r], 1)];
+            qz = ws[c.prp + pair8(l[r], 2)];
         }
         qx2[r] = splat(qx);
         qy2[r] = splat(qy);
@@ -353,6 +660,342 @@ __global__ __launch_bounds__(kThreads) void emd_rows2_kernel(Ctx c, int lev, flo
         work(b0, b1);
         if (R == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(acc2[0]));
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(acc2[0]), "+v"(acc2[R - 1]));
+    }
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        acc[r] = acc2[r].x + acc2[r].y;
+        parts[part][r * kRowsPerWg + lrow] = acc[r];
+    }
+    __syncthreads();
+    if (part != 0) return;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (!ok[r]) continue;
+        float a = acc[r];
+#pragma unroll
+        for (int q2 = 1; q2 < kParts; ++q2) a += parts[q2][r * kRowsPerWg + lrow];
+        const float rr = remR[l[r]];
+        const float sumr = a * rr;
+        const float consumption = fminf(rr / (sumr + 1e-9f), 1.0f);
+        const float v = consumption * rr;
+        const float rem = fmaxf(0.0f, rr - sumr);
+        ratioR[l[r]] = v;
+        remR[l[r]] = rem;
+        ws[c.prp + pair8(l[r], 3)] = v;
+        ws[c.rr + l[r]] = rem;
+        ws[c.frp + pair32(l[r], 3 + lev)] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Culling sweeps (records in k-d order).  Same rows, same candidates, same arithmetic per (row, candidate) as emd_rows1_kernel /
+// emd_rows2_kernel; the candidate set of a wave is cut into blocks of 8 (one pipeline stage), block g belongs to candidate range
+// (g mod kParts) — interleaved, so that the blocks near a row tile spread over the four waves —, and a (64-row tile, block) unit is
+// evaluated only if the two bounding boxes are closer than the level's underflow radius.  Every skipped term is an exact zero
+// (exp2 of less than -152; fma(0, w, acc) == acc), so a row's sum is the sum over its surviving blocks in ascending order — the
+// reference's sum with its zero terms left out.  The decision is taken per 64-row tile whatever R is: every rows-per-lane
+// instance still evaluates each row identically.  Lane i of a wave tests block i of its range (one ballot per row tile), the
+// surviving blocks are walked with s_ff1 on the masks, their records prefetched one block ahead on the scalar path as before.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float box_gap2(const float (&tlo)[3], const float (&thi)[3], float cx0, float cy0, float cz0, float cx1, float cy1,
+                                          float cz1) {
+    const float gx = fmaxf(0.f, fmaxf(cx0 - thi[0], tlo[0] - cx1));
+    const float gy = fmaxf(0.f, fmaxf(cy0 - thi[1], tlo[1] - cy1));
+    const float gz = fmaxf(0.f, fmaxf(cz0 - thi[2], tlo[2] - cz1));
+    return gx * gx + gy * gy + gz * gz;
+}
+// tile t's box (uniform address: scalar loads); tiles past the last one are empty
+__device__ __forceinline__ void load_tile_box(const float* tb, int NT, int t, float (&lo)[3], float (&hi)[3]) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        lo[q] = t < NT ? tb[q * NT + t] : kFar;
+        hi[q] = t < NT ? tb[(3 + q) * NT + t] : -kFar;
+    }
+}
+
+template <bool DO3, bool DO1, int R>
+__global__ __launch_bounds__(kThreads) void emd_rows1_cull_kernel(Ctx c, int lev1, float l2e3, float l2e1, float thr3, float thr1) {
+    __shared__ float part3[kParts][kRowsPerWg * R], part1[kParts][kRowsPerWg * R];
+    const int cloud = blockIdx.y;
+    const int lrow = threadIdx.x % kRowsPerWg;
+    const int part = __builtin_amdgcn_readfirstlane(threadIdx.x / kRowsPerWg);   // wave-uniform
+    float* ws = c.ws + (long)cloud * c.per_cloud;
+    float* remL = c.temp + (long)cloud * (c.n + c.m) * 2;
+    float* ratioL = remL + c.n + c.m;
+    int k[R];
+    bool ok[R];
+    f2 px2[R], py2[R], pz2[R], rl2[R], acc3[R], acc1[R];
+    float tlo[R][3], thi[R][3];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        k[r] = (blockIdx.x * R + r) * kRowsPerWg + lrow;
+        ok[r] = k[r] < c.n;
+        float px = 0.f, py = 0.f, pz = 0.f, rl = 0.f;
+        if (ok[r]) {
+            px = ws[c.plp + pair8(k[r], 0)];
+            py = ws[c.plp + pair8(k[r], 1)];
+            pz = ws[c.plp + pair8(k[r], 2)];
+            if (DO3) rl = ratioL[k[r]];
+        }
+        px2[r] = splat(px);
+        py2[r] = splat(py);
+        pz2[r] = splat(pz);
+        rl2[r] = splat(rl);
+        acc3[r] = splat(0.f);
+        acc1[r] = f2{part == 0 ? 1e-9f : 0.f, 0.f};
+        load_tile_box(ws + c.tileL, c.NP / kTile, blockIdx.x * R + r, tlo[r], thi[r]);
+    }
+    const f2 l3 = splat(l2e3), l1 = splat(l2e1);
+    const int NB = c.MP / kBlk, nblk = NB / kParts;          // blocks of the set, blocks of this wave's range (g = i * kParts + part)
+    const float* bb = ws + c.blkR;
+    const float* prec = ws + c.prp;
+    const float* wrec = ws + c.rr;
+    const int lane = threadIdx.x & 63;
+    f32x16 a0, a1, b0, b1;
+    f32x8 w0 = {}, w1 = {};
+    for (int ch = 0; ch < nblk; ch += 64) {
+        // which blocks of this chunk can any row of tile r reach at the level of phase 1 (mask1) / phase 3 (mask3 <= mask1)
+        unsigned long long mask1[R], mask3[R], any = 0ull;
+        {
+            const int i = ch + lane;
+            const bool valid = i < nblk;
+            const int g = valid ? i * kParts + part : 0;
+            const float cx0 = bb[g], cy0 = bb[NB + g], cz0 = bb[2 * NB + g], cx1 = bb[3 * NB + g], cy1 = bb[4 * NB + g], cz1 = bb[5 * NB + g];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float g2 = box_gap2(tlo[r], thi[r], cx0, cy0, cz0, cx1, cy1, cz1);
+                mask3[r] = DO3 ? __ballot(valid && g2 <= thr3) : 0ull;
+                mask1[r] = DO1 ? __ballot(valid && g2 <= thr1) : mask3[r];
+                any |= mask1[r];
+            }
+        }
+        auto work = [&](const f32x16& lo, const f32x16& hi, const f32x8& w, int bi) {
+            if (R > 1) {      // every row tile of the wave reaches the block at both levels: the interleaved form of emd_rows1_kernel
+                bool all = true;
+#pragma unroll
+                for (int r = 0; r < R; ++r) all = all && (((DO3 ? mask3[r] : mask1[r]) >> bi) & 1ull);
+                if (all) {
+#pragma unroll
+                    for (int u = 0; u < kStage / 2; ++u) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const f2 d = sqdist2(PAIRC(lo, hi, u, 0) - px2[r], PAIRC(lo, hi, u, 1) - py2[r], PAIRC(lo, hi, u, 2) - pz2[r]);
+                            if (DO3) acc3[r] = __builtin_elementwise_fma(exp2_2(l3 * d) * rl2[r], PAIRC(lo, hi, u, 3), acc3[r]);
+                            if (DO1) acc1[r] = __builtin_elementwise_fma(exp2_2(l1 * d), f2{w[u * 2], w[u * 2 + 1]}, acc1[r]);
+                        }
+                    }
+                    return;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (!((mask1[r] >> bi) & 1ull)) continue;
+                const bool on3 = DO3 && ((mask3[r] >> bi) & 1ull);
+                if (on3 || !DO1) {
+#pragma unroll
+                    for (int u = 0; u < kStage / 2; ++u) {
+                        const f2 d = sqdist2(PAIRC(lo, hi, u, 0) - px2[r], PAIRC(lo, hi, u, 1) - py2[r], PAIRC(lo, hi, u, 2) - pz2[r]);
+                        acc3[r] = __builtin_elementwise_fma(exp2_2(l3 * d) * rl2[r], PAIRC(lo, hi, u, 3), acc3[r]);   // (e * ratioL[k]) * ratioR[l]
+                        if (DO1) acc1[r] = __builtin_elementwise_fma(exp2_2(l1 * d), f2{w[u * 2], w[u * 2 + 1]}, acc1[r]);   // e * remainR[l]
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < kStage / 2; ++u) {
+                        const f2 d = sqdist2(PAIRC(lo, hi, u, 0) - px2[r], PAIRC(lo, hi, u, 1) - py2[r], PAIRC(lo, hi, u, 2) - pz2[r]);
+                        acc1[r] = __builtin_elementwise_fma(exp2_2(l1 * d), f2{w[u * 2], w[u * 2 + 1]}, acc1[r]);
+                    }
+                }
+            }
+        };
+        if (any == 0ull) continue;
+        int ia = __builtin_ctzll(any), ib = 0;
+        any &= any - 1ull;
+        {
+            const long g = (long)(ch + ia) * kParts + part;
+            const float* p = prec + g * (kBlk * 4);
+            const float* q = wrec + g * kBlk;
+            HP_SLOAD16(a0, p, 0x0);
+            HP_SLOAD16(a1, p, 0x40);
+            if (DO1) HP_SLOAD8(w0, q, 0x0);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+s"(w0));
+        }
+        while (true) {
+            const bool more_b = any != 0ull;
+            if (more_b) {
+                ib = __builtin_ctzll(any);
+                any &= any - 1ull;
+                const long g = (long)(ch + ib) * kParts + part;
+                const float* p = prec + g * (kBlk * 4);
+                const float* q = wrec + g * kBlk;
+                HP_SLOAD16(b0, p, 0x0);
+                HP_SLOAD16(b1, p, 0x40);
+                if (DO1) HP_SLOAD8(w1, q, 0x0);
+            }
+            HP_PIN();
+            work(a0, a1, w0, ia);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1), "+s"(w1), "+v"(acc3[0]), "+v"(acc1[0]), "+v"(acc3[R - 1]), "+v"(acc1[R - 1]));
+            if (!more_b) break;
+            const bool more_a = any != 0ull;
+            if (more_a) {
+                ia = __builtin_ctzll(any);
+                any &= any - 1ull;
+                const long g = (long)(ch + ia) * kParts + part;
+                const float* p = prec + g * (kBlk * 4);
+                const float* q = wrec + g * kBlk;
+                HP_SLOAD16(a0, p, 0x0);
+                HP_SLOAD16(a1, p, 0x40);
+                if (DO1) HP_SLOAD8(w0, q, 0x0);
+            }
+            HP_PIN();
+            work(b0, b1, w1, ib);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+s"(w0), "+v"(acc3[0]), "+v"(acc1[0]), "+v"(acc3[R - 1]), "+v"(acc1[R - 1]));
+            if (!more_a) break;
+        }
+    }
+    float s3[R], s1[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        s3[r] = acc3[r].x + acc3[r].y;
+        s1[r] = acc1[r].x + acc1[r].y;
+        part3[part][r * kRowsPerWg + lrow] = s3[r];
+        part1[part][r * kRowsPerWg + lrow] = s1[r];
+    }
+    __syncthreads();
+    if (part != 0) return;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (!ok[r]) continue;
+        float t3 = s3[r], t1 = s1[r];
+#pragma unroll
+        for (int q2 = 1; q2 < kParts; ++q2) {
+            t3 += part3[q2][r * kRowsPerWg + lrow];
+            t1 += part1[q2][r * kRowsPerWg + lrow];
+        }
+        float rem = remL[k[r]];
+        if (DO3) {
+            rem = fmaxf(0.0f, rem - t3);
+            remL[k[r]] = rem;
+        }
+        if (DO1) {
+            const float v = rem / t1;
+            ratioL[k[r]] = v;
+            ws[c.plp + pair8(k[r], 3)] = v;
+            ws[c.flp + pair32(k[r], 3 + lev1)] = v;
+        }
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(kThreads) void emd_rows2_cull_kernel(Ctx c, int lev, float l2e, float thr) {
+    __shared__ float parts[kParts][kRowsPerWg * R];
+    const int cloud = blockIdx.y;
+    const int lrow = threadIdx.x % kRowsPerWg;
+    const int part = __builtin_amdgcn_readfirstlane(threadIdx.x / kRowsPerWg);
+    float* ws = c.ws + (long)cloud * c.per_cloud;
+    float* remR = c.temp + (long)cloud * (c.n + c.m) * 2 + c.n;
+    float* ratioR = remR + c.m + c.n;
+    int l[R];
+    bool ok[R];
+    f2 qx2[R], qy2[R], qz2[R], acc2[R];
+    float tlo[R][3], thi[R][3];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        l[r] = (blockIdx.x * R + r) * kRowsPerWg + lrow;
+        ok[r] = l[r] < c.m;
+        float qx = 0.f, qy = 0.f, qz = 0.f;
+        if (ok[r]) {
+            qx = ws[c.prp + pair8(l[r], 0)];
+            qy = ws[c.prp + pair8(l[r], 1)];
+            qz = ws[c.prp + pair8(l[r], 2)];
+        }
+        qx2[r] = splat(qx);
+        qy2[r] = splat(qy);
+        qz2[r] = splat(qz);
+        acc2[r] = splat(0.f);
+        load_tile_box(ws + c.tileR, c.MP / kTile, blockIdx.x * R + r, tlo[r], thi[r]);
+    }
+    const f2 lv = splat(l2e);
+    const int NB = c.NP / kBlk, nblk = NB / kParts;
+    const float* bb = ws + c.blkL;
+    const float* prec = ws + c.plp;
+    const int lane = threadIdx.x & 63;
+    f32x16 a0, a1, b0, b1;
+    for (int ch = 0; ch < nblk; ch += 64) {
+        unsigned long long mask[R], any = 0ull;
+        {
+            const int i = ch + lane;
+            const bool valid = i < nblk;
+            const int g = valid ? i * kParts + part : 0;
+            const float cx0 = bb[g], cy0 = bb[NB + g], cz0 = bb[2 * NB + g], cx1 = bb[3 * NB + g], cy1 = bb[4 * NB + g], cz1 = bb[5 * NB + g];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                mask[r] = __ballot(valid && box_gap2(tlo[r], thi[r], cx0, cy0, cz0, cx1, cy1, cz1) <= thr);
+                any |= mask[r];
+            }
+        }
+        auto work = [&](const f32x16& lo, const f32x16& hi, int bi) {
+            if (R > 1) {      // every row tile of the wave reaches the block: the interleaved form of emd_rows2_kernel
+                bool all = true;
+#pragma unroll
+                for (int r = 0; r < R; ++r) all = all && ((mask[r] >> bi) & 1ull);
+                if (all) {
+#pragma unroll
+                    for (int u = 0; u < kStage / 2; ++u) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const f2 d = sqdist2(qx2[r] - PAIRC(lo, hi, u, 0), qy2[r] - PAIRC(lo, hi, u, 1), qz2[r] - PAIRC(lo, hi, u, 2));
+                            acc2[r] = __builtin_elementwise_fma(exp2_2(lv * d), PAIRC(lo, hi, u, 3), acc2[r]);
+                        }
+                    }
+                    return;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (!((mask[r] >> bi) & 1ull)) continue;
+#pragma unroll
+                for (int u = 0; u < kStage / 2; ++u) {
+                    const f2 d = sqdist2(qx2[r] - PAIRC(lo, hi, u, 0), qy2[r] - PAIRC(lo, hi, u, 1), qz2[r] - PAIRC(lo, hi, u, 2));
+                    acc2[r] = __builtin_elementwise_fma(exp2_2(lv * d), PAIRC(lo, hi, u, 3), acc2[r]);   // approxmatch.cu:131-132 contracted
+                }
+            }
+        };
+        if (any == 0ull) continue;
+        int ia = __builtin_ctzll(any), ib = 0;
+        any &= any - 1ull;
+        {
+            const float* p = prec + ((long)(ch + ia) * kParts + part) * (kBlk * 4);
+            HP_SLOAD16(a0, p, 0x0);
+            HP_SLOAD16(a1, p, 0x40);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1));
+        }
+        while (true) {
+            const bool more_b = any != 0ull;
+            if (more_b) {
+                ib = __builtin_ctzll(any);
+                any &= any - 1ull;
+                const float* p = prec + ((long)(ch + ib) * kParts + part) * (kBlk * 4);
+                HP_SLOAD16(b0, p, 0x0);
+                HP_SLOAD16(b1, p, 0x40);
+            }
+            HP_PIN();
+            work(a0, a1, ia);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1), "+v"(acc2[0]), "+v"(acc2[R - 1]));
+            if (!more_b) break;
+            const bool more_a = any != 0ull;
+            if (more_a) {
+                ia = __builtin_ctzll(any);
+                any &= any - 1ull;
+                const float* p = prec + ((long)(ch + ia) * kParts + part) * (kBlk * 4);
+                HP_SLOAD16(a0, p, 0x0);
+                HP_SLOAD16(a1, p, 0x40);
+            }
+            HP_PIN();
+            work(b0, b1, ib);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(acc2[0]), "+v"(acc2[R - 1]));
+            if (!more_a) break;
+        }
     }
     float acc[R];
 #pragma unroll
@@ -531,7 +1174,9 @@ __global__ __launch_bounds__(kThreads) void emd_cost_grad1_kernel(Ctx c, float* 
             cost += parts[q2][3][lrow];
         }
         if (ok && grad1) {
-            float* g = grad1 + ((long)cloud * c.n + k) * 3;
+            // records in k-d order (emd_order_kernel): position k holds the caller's point permL[k]
+            const int ko = ws[c.flag] != 0.f ? reinterpret_cast<const int*>(ws + c.permL)[k] : k;
+            float* g = grad1 + ((long)cloud * c.n + ko) * 3;
             g[0] = dx;
             g[1] = dy;
             g[2] = dz;
@@ -631,7 +1276,8 @@ __global__ __launch_bounds__(kThreads) void emd_grad2_kernel(Ctx c, float* __res
                 cost[r] += parts[q2][3][r * kRowsPerWg + lrow];
             }
             if (ok[r]) {
-                float* g = grad2 + ((long)cloud * c.m + l[r]) * 3;
+                const int lo = ws[c.flag] != 0.f ? reinterpret_cast<const int*>(ws + c.permR)[l[r]] : l[r];   // see emd_cost_grad1_kernel
+                float* g = grad2 + ((long)cloud * c.m + lo) * 3;
                 if (c.acc_scale != 0.f) {   // hp_emd_forward_acc: the caller's running gradient (+= coef * this term)
                     g[0] = __builtin_fmaf(c.acc_scale, sx[r], g[0]);
                     g[1] = __builtin_fmaf(c.acc_scale, sy[r], g[1]);
@@ -676,12 +1322,24 @@ struct LevelChain {
     bool final_remainL;
     float multiL, multiR;
     int rows1_r, rows2_r;
+    int cull;                      // > 0: records in k-d order, sweeps of levels < cull skip the units that are exactly zero
+    int logpL = 0, logpR = 0;      // log2 of the order kernel's sort sizes
+    int cull_r = 0;                // rows per lane of the culling instances (0: rows1_r / rows2_r)
     dim3 ginit, g1[3], g2[3];      // grids at 1, 2, 4 rows per lane
 
-    LevelChain(int b_, int n, int m, const float* xyz1, const float* xyz2, float* temp, float* ws, hipStream_t st, bool frl)
-        : b(b_), stream(st), final_remainL(frl) {
+    static int log2_ceil64(int x) {
+        int l = 6;
+        while ((1 << l) < x) ++l;
+        return l;
+    }
+    // largest squared distance whose exponential at `lev` is not exactly zero (exp2 of less than -152 is +0 in fp32, denormals
+    // included; the margin over -150 covers the rounding of the box test and of the kernels' own distance)
+    float radius2(int lev) const { return lev < cull ? 152.f / -level_l2e(lev) : 3.0e38f; }
+
+    LevelChain(int b_, int n, int m, const float* xyz1, const float* xyz2, float* temp, float* ws, hipStream_t st, bool frl, int cull_)
+        : b(b_), stream(st), final_remainL(frl), cull(cull_) {
         const WsLayout L = ws_layout(n, m);
-        c = Ctx{n, m, L.NP, L.MP, xyz1, xyz2, temp, ws, L.plp, L.prp, L.rr, L.flp, L.frp, L.per_cloud};
+        c = make_ctx(n, m, xyz1, xyz2, temp, ws);
         if (n >= m) {
             multiL = 1;
             multiR = (float)(n / m);  // integer division (approxmatch.cu:37-43)
@@ -689,6 +1347,9 @@ struct LevelChain {
             multiL = (float)(m / n);
             multiR = 1;
         }
+        logpL = log2_ceil64(n);
+        logpR = log2_ceil64(m);
+        if (logpL > kOrderMaxLog || logpR > kOrderMaxLog) cull = 0;
         for (int i = 0; i < 3; ++i) {
             const int r = 1 << i;
             g1[i] = dim3((n + r * kRowsPerWg - 1) / (r * kRowsPerWg), b);
@@ -707,37 +1368,68 @@ struct LevelChain {
         const int f1 = g_rows1.load(std::memory_order_relaxed), f2 = g_rows2.load(std::memory_order_relaxed);
         rows1_r = f1 ? f1 : pick(n, 2);
         rows2_r = f2 ? f2 : pick(m, 4);
+        cull_r = g_cull_rows.load(std::memory_order_relaxed);
     }
 
+    // phase 3 of level lev3 (D3) merged with phase 1 of level lev1 (D1)
     template <bool D3, bool D1>
-    void rows1(int lev1, float l2e3, float l2e1) const {
-        if (rows1_r == 4) hipLaunchKernelGGL((emd_rows1_kernel<D3, D1, 4>), g1[2], dim3(kThreads), 0, stream, c, lev1, l2e3, l2e1);
-        else if (rows1_r == 2) hipLaunchKernelGGL((emd_rows1_kernel<D3, D1, 2>), g1[1], dim3(kThreads), 0, stream, c, lev1, l2e3, l2e1);
-        else hipLaunchKernelGGL((emd_rows1_kernel<D3, D1, 1>), g1[0], dim3(kThreads), 0, stream, c, lev1, l2e3, l2e1);
+    void rows1(int lev3, int lev1) const {
+        const float l2e3 = D3 ? level_l2e(lev3) : 0.f, l2e1 = D1 ? level_l2e(lev1) : 0.f;
+        int i = rows1_r == 4 ? 2 : rows1_r == 2 ? 1 : 0;
+        if (cull > 0 && (D3 ? lev3 : lev1) < cull) {     // (lev3 < lev1: the launch culls if its finer level does)
+            const float t3 = D3 ? radius2(lev3) : 0.f, t1 = D1 ? radius2(lev1) : 0.f;
+            const int cr = cull_r ? cull_r : rows1_r;
+            i = cr == 4 ? 2 : cr == 2 ? 1 : 0;
+            if (cr == 4) hipLaunchKernelGGL((emd_rows1_cull_kernel<D3, D1, 4>), g1[i], dim3(kThreads), 0, stream, c, lev1, l2e3, l2e1, t3, t1);
+            else if (cr == 2) hipLaunchKernelGGL((emd_rows1_cull_kernel<D3, D1, 2>), g1[i], dim3(kThreads), 0, stream, c, lev1, l2e3, l2e1, t3, t1);
+            else hipLaunchKernelGGL((emd_rows1_cull_kernel<D3, D1, 1>), g1[i], dim3(kThreads), 0, stream, c, lev1, l2e3, l2e1, t3, t1);
+            return;
+        }
+        if (rows1_r == 4) hipLaunchKernelGGL((emd_rows1_kernel<D3, D1, 4>), g1[i], dim3(kThreads), 0, stream, c, lev1, l2e3, l2e1);
+        else if (rows1_r == 2) hipLaunchKernelGGL((emd_rows1_kernel<D3, D1, 2>), g1[i], dim3(kThreads), 0, stream, c, lev1, l2e3, l2e1);
+        else hipLaunchKernelGGL((emd_rows1_kernel<D3, D1, 1>), g1[i], dim3(kThreads), 0, stream, c, lev1, l2e3, l2e1);
     }
     void rows2(int lev) const {
-        if (rows2_r == 4) hipLaunchKernelGGL(emd_rows2_kernel<4>, g2[2], dim3(kThreads), 0, stream, c, lev, level_l2e(lev));
-        else if (rows2_r == 2) hipLaunchKernelGGL(emd_rows2_kernel<2>, g2[1], dim3(kThreads), 0, stream, c, lev, level_l2e(lev));
-        else hipLaunchKernelGGL(emd_rows2_kernel<1>, g2[0], dim3(kThreads), 0, stream, c, lev, level_l2e(lev));
+        int i = rows2_r == 4 ? 2 : rows2_r == 2 ? 1 : 0;
+        if (cull > 0 && lev < cull) {
+            const float t = radius2(lev);
+            const int cr = cull_r ? cull_r : rows2_r;
+            i = cr == 4 ? 2 : cr == 2 ? 1 : 0;
+            if (cr == 4) hipLaunchKernelGGL(emd_rows2_cull_kernel<4>, g2[i], dim3(kThreads), 0, stream, c, lev, level_l2e(lev), t);
+            else if (cr == 2) hipLaunchKernelGGL(emd_rows2_cull_kernel<2>, g2[i], dim3(kThreads), 0, stream, c, lev, level_l2e(lev), t);
+            else hipLaunchKernelGGL(emd_rows2_cull_kernel<1>, g2[i], dim3(kThreads), 0, stream, c, lev, level_l2e(lev), t);
+            return;
+        }
+        if (rows2_r == 4) hipLaunchKernelGGL(emd_rows2_kernel<4>, g2[i], dim3(kThreads), 0, stream, c, lev, level_l2e(lev));
+        else if (rows2_r == 2) hipLaunchKernelGGL(emd_rows2_kernel<2>, g2[i], dim3(kThreads), 0, stream, c, lev, level_l2e(lev));
+        else hipLaunchKernelGGL(emd_rows2_kernel<1>, g2[i], dim3(kThreads), 0, stream, c, lev, level_l2e(lev));
     }
     static constexpr int kSteps = 2 + 2 * kLevels;
     void step(int s) const {
         if (s == 0) {
-            hipLaunchKernelGGL(emd_init_kernel, ginit, dim3(256), 0, stream, c, multiL, multiR);
+            if (cull > 0) {
+                const int lp = std::max(logpL, logpR);
+                const size_t lds = (size_t)19 << lp;    // 16 bytes per point (x, y, z, key) + P2/8 block boxes of 24 bytes
+                if (lds > 48 * 1024)
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(emd_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(emd_order_kernel, dim3(2, b), dim3(kOrderThreads), lds, stream, c, multiL, multiR, logpL, logpR);
+            } else {
+                hipLaunchKernelGGL(emd_init_kernel, ginit, dim3(256), 0, stream, c, multiL, multiR);
+            }
         } else if (s == 1) {
-            rows1<false, true>(0, 0.f, level_l2e(0));
+            rows1<false, true>(0, 0);
         } else {
             const int lev = (s - 2) >> 1;
             if (((s - 2) & 1) == 0) rows2(lev);
-            else if (lev + 1 < kLevels) rows1<true, true>(lev + 1, level_l2e(lev), level_l2e(lev + 1));
-            else if (final_remainL) rows1<true, false>(lev, level_l2e(lev), 0.f);
+            else if (lev + 1 < kLevels) rows1<true, true>(lev, lev + 1);
+            else if (final_remainL) rows1<true, false>(lev, lev);
         }
     }
 };
 
 int run_levels(int b, int n, int m, const float* xyz1, const float* xyz2, float* temp, float* ws, Ctx* out, hipStream_t stream,
-               bool final_remainL) {
-    const LevelChain ch(b, n, m, xyz1, xyz2, temp, ws, stream, final_remainL);
+               bool final_remainL, int cull) {
+    const LevelChain ch(b, n, m, xyz1, xyz2, temp, ws, stream, final_remainL, cull);
     for (int s = 0; s < LevelChain::kSteps; ++s) ch.step(s);
     *out = ch.c;
     return (int)hipGetLastError();
@@ -848,6 +1540,14 @@ HP_API int hp_emd_set_rows_per_lane(int rows1, int rows2, int grad2) {
 // from v_exp_f32 (0); returns the previous setting.  `match` as hp_approxmatch* return it is never derived.
 HP_API int hp_emd_set_final_derive(int on) { return g_final_derive.exchange(on != 0); }
 
+// hp_emd_forward* / hp_emd_forward_acc: the records in k-d order and the sweeps of the first `levels` annealing levels skipping the
+// (64-row tile, 8-candidate block) units whose terms are all exactly zero (emd_order_kernel, emd_rows*_cull_kernel); 0 = the
+// caller's point order, every unit evaluated (rounds 1-5).  Default 4 (HP_EMD_CULL at load time).  Returns the previous setting.
+HP_API int hp_emd_set_cull(int levels) {
+    HP_CHECK_ARG(levels >= 0 && levels <= kLevels);
+    return g_cull.exchange(levels);
+}
+
 // hp_emd_forward* as two chains of half the clouds on two streams (2, default) or as one chain (1); returns the previous setting.
 HP_API int hp_emd_set_chains(int chains) {
     HP_CHECK_ARG(chains == 1 || chains == 2);
@@ -890,7 +1590,7 @@ HP_API int hp_approxmatch_ws(int b, int n, int m, const float* xyz1, const float
     if (b == 0) return 0;
     HP_CHECK_ARG(xyz1 && xyz2 && match && temp && ws && b <= 65535);
     Ctx c;
-    int rc = run_levels(b, n, m, xyz1, xyz2, temp, ws, &c, stream, true);
+    int rc = run_levels(b, n, m, xyz1, xyz2, temp, ws, &c, stream, true, 0);   // `match` and `temp` leave in the caller's order
     if (rc) return rc;
     hipLaunchKernelGGL(emd_match_kernel, dim3((n + kThreads - 1) / kThreads, (m + kLT - 1) / kLT, b), dim3(kThreads), 0, stream, c,
                        match);
@@ -930,7 +1630,7 @@ int emd_final_sweep(Ctx c, int b, float* partials, float* cost, float* grad1, fl
 int emd_forward_chain(int b, int n, int m, const float* xyz1, const float* xyz2, float* temp, float* ws, float* partials,
                       float* cost, float* grad1, float* grad2, float acc_scale, hipStream_t stream, hipStream_t after) {
     Ctx c;
-    int rc = run_levels(b, n, m, xyz1, xyz2, temp, ws, &c, stream, false);   // temp is scratch here
+    int rc = run_levels(b, n, m, xyz1, xyz2, temp, ws, &c, stream, false, g_cull.load(std::memory_order_relaxed));   // temp is scratch here
     if (rc) return rc;
     return emd_final_sweep(c, b, partials, cost, grad1, grad2, acc_scale, stream, after);
 }
@@ -1021,9 +1721,10 @@ int emd_forward_impl(int b, int n, int m, const float* xyz1, const float* xyz2, 
     const WsLayout L = ws_layout(n, m);
     int rc = hp_order_streams(stream, s2);                                       // the inputs are ready on `stream`
     if (rc) return rc;
-    const LevelChain c0(h, n, m, xyz1, xyz2, temp, ws, stream, false);
+    const int cull = g_cull.load(std::memory_order_relaxed);
+    const LevelChain c0(h, n, m, xyz1, xyz2, temp, ws, stream, false, cull);
     const LevelChain c1(b - h, n, m, xyz1 + (long)h * n * 3, xyz2 + (long)h * m * 3, temp + (long)h * (n + m) * 2, ws + (long)h * L.per_cloud,
-                        s2, false);
+                        s2, false, cull);
     for (int st = 0; st < LevelChain::kSteps; ++st) {      // alternately: both streams are fed at the same pace
         c0.step(st);
         c1.step(st);
@@ -1054,8 +1755,7 @@ HP_API int hp_emd_backward(int b, int n, int m, const float* xyz1, const float* 
     HP_CHECK_ARG(b >= 0 && n > 0 && m > 0);
     if (b == 0) return 0;
     HP_CHECK_ARG(ws && grad2 && b <= 65535);
-    const WsLayout L = ws_layout(n, m);
-    Ctx c{n, m, L.NP, L.MP, xyz1, xyz2, nullptr, const_cast<float*>(ws), L.plp, L.prp, L.rr, L.flp, L.frp, L.per_cloud};
+    Ctx c = make_ctx(n, m, xyz1, xyz2, nullptr, const_cast<float*>(ws));
     const dim3 grid((m + kRowsPerWg - 1) / kRowsPerWg, b);
     if (g_final_derive.load(std::memory_order_relaxed)) hipLaunchKernelGGL((emd_grad2_kernel<false, 1, true>), grid, dim3(kThreads), 0, stream, c, grad2, nullptr);
     else hipLaunchKernelGGL((emd_grad2_kernel<false, 1, false>), grid, dim3(kThreads), 0, stream, c, grad2, nullptr);

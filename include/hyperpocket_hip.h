@@ -13,7 +13,7 @@
  *      approxmatch.cu:334-337; its nndistance launchers check nothing, nndistance.cu:131-160).
  * Layouts are the reference's: point sets (b, n, 3) fp32 contiguous, indices int32.
  *
- * TEST HOOKS.  hp_emd_set_rows_per_lane, hp_emd_set_final_derive, hp_emd_set_chains, hp_encoder_backward_set_fused, hp_encoder_backward_set_chain_f16, hp_hypernet_set_heads_stream, hp_conv_split_set, hp_skinny_set_enabled,
+ * TEST HOOKS.  hp_emd_set_rows_per_lane, hp_emd_set_final_derive, hp_emd_set_chains, hp_emd_set_cull, hp_encoder_backward_set_fused, hp_encoder_backward_set_chain_f16, hp_hypernet_set_heads_stream, hp_conv_split_set, hp_skinny_set_enabled,
  * hp_target_fused_set_f16 (and hp_conv_presplit_set below) flip PROCESS-WIDE switches that select between implementations of
  * the same result; they exist so that the parity tests can hold every implementation against the oracle in one process.  They
  * are plain globals: not thread-safe, not per-stream, not meant to be called while another host thread is inside the library.
@@ -78,6 +78,17 @@ int hp_emd_set_final_derive(int on);
  * environment HP_EMD_CHAINS=1 at load time): two chains; 1: one.  Returns the previous setting. */
 /* [test hook: process-wide, not thread-safe — see the header comment] */
 int hp_emd_set_chains(int chains);
+/* hp_emd_forward / hp_emd_forward_acc put both point sets in a k-d order first (one workgroup per cloud and set; 2^k-aligned runs
+ * of positions are boxes of 2^k points) and the sweeps of the first `levels` annealing levels skip every (64-row tile, 8-candidate
+ * block) unit whose bounding boxes are further apart than the level's underflow radius (d^2 > 152 ln2 / |level|: each of its
+ * exponentials is exactly +0 in fp32, so each skipped term of approxmatch.cu:86-87,131-132,185-189 is an exact zero).  Results:
+ * the sums of the caller's order with their zero terms left out, accumulated in the k-d order (cost within 3e-7 of the same
+ * kernels on the caller's order); gradients are written through the permutation, so callers keep their own point order.
+ * levels in 0..9; 0 = the caller's order, every unit evaluated (rounds 1-5).  Default 4 (environment HP_EMD_CULL at load time).
+ * Sets of more than 4096 points always run in the caller's order.  hp_approxmatch / hp_approxmatch_ws (whose `match` and `temp`
+ * are returned in the caller's order) are never re-ordered.  Returns the previous setting. */
+/* [test hook: process-wide, not thread-safe — see the header comment] */
+int hp_emd_set_cull(int levels);
 
 /* Match-free EMD (what match_cost.py:9-46 computes through ApproxMatch + MatchCost + MatchCostGrad, without ever
  * writing the (b,m,n) match tensor): cost (b,) plus whichever of grad1 = d cost/d xyz1, grad2 = d cost/d xyz2 the

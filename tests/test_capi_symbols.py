@@ -48,9 +48,11 @@ def test_library_exports_every_declared_symbol(lib):
 def test_workspace_queries_run_on_host(lib):
     lib.hp_approxmatch_workspace_floats.restype = ctypes.c_long
     lib.hp_target_theta_size.restype = ctypes.c_long
-    # packed candidate records of emd.hip: (N+8)*(4+16) + (M+8)*(4+1+16) floats per cloud, N and M padded to 16
-    assert lib.hp_approxmatch_workspace_floats(64, 2048, 2048) == 64 * (2056 * 20 + 2056 * 21)
-    assert lib.hp_approxmatch_workspace_floats(1, 100, 37) == (128 + 8) * 20 + (64 + 8) * 21   # padded to multiples of 64
+    # packed candidate records of emd.hip: (N+8)*(4+16) + (M+8)*(4+1+16) floats per cloud, N and M padded to multiples of 64;
+    # round 6: + per set the k-d permutation (1 per point), block boxes (6 per 8 points), tile boxes (6 per 64 points), + 16 (flag)
+    extra = lambda P: P + 6 * (P // 8) + 6 * (P // 64)
+    assert lib.hp_approxmatch_workspace_floats(64, 2048, 2048) == 64 * (2056 * 20 + 2056 * 21 + 2 * extra(2048) + 16)
+    assert lib.hp_approxmatch_workspace_floats(1, 100, 37) == (128 + 8) * 20 + (64 + 8) * 21 + extra(128) + extra(64) + 16
     ch = (ctypes.c_int * 4)(32, 64, 128, 64)
     assert lib.hp_target_theta_size(4, ch) == 19011
     assert lib.hp_target_theta_size(0, ch) == -1
