@@ -35,6 +35,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <vector>
 
 // (Round 3's derived-exponential experiment — e(j) = e(j+1)^4, -0.08 ms per step, fails the parity bars — lives as a patch in
 // tools/micro/emd_derive.patch, not in the shipped library: DESIGN.md 7b.)
@@ -117,13 +118,13 @@ inline int env_rows(const char* name) {
 std::mutex g_s2_mu;                            // the library's second-chain stream per device (emd_forward_impl)
 std::map<int, hipStream_t> g_s2_streams;
 // hp_emd_forward* as two chains of half the clouds on two streams (2) or one chain (1): emd_forward_impl
-std::atomic<int> g_chains{[] { const char* e = getenv("HP_EMD_CHAINS"); const int v = e ? atoi(e) : 2; return v == 1 ? 1 : 2; }()};
+constexpr int kMaxChains = 4;
+std::atomic<int> g_chains{[] { const char* e = getenv("HP_EMD_CHAINS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v > kMaxChains ? kMaxChains : v; }()};
 // the final cost / gradient sweep with derived exponentials (match_entry2<.., DERIVE>): on unless HP_EMD_FINAL_DERIVE=0
 std::atomic<int> g_final_derive{[] { const char* e = getenv("HP_EMD_FINAL_DERIVE"); return (e && atoi(e) == 0) ? 0 : 1; }()};
 // hp_emd_forward*: records in k-d order and the first g_cull levels' sweeps culling (0: caller's order, no culling): hp_emd_set_cull
-constexpr int kCullDefault = 4;
+constexpr int kCullDefault = 3;
 std::atomic<int> g_cull{[] { const char* e = getenv("HP_EMD_CULL"); const int v = e ? atoi(e) : kCullDefault; return v < 0 ? 0 : v > kLevels ? kLevels : v; }()};
-std::atomic<int> g_cull_rows{env_rows("HP_EMD_CULL_R")};   // rows per lane of the culling instances (0: as the plain ones)
 constexpr int kOrderMaxLog = 12;   // k-d order for sets of up to 4096 points (the order kernel's LDS: 19 bytes per point)
 std::atomic<int> g_rows1{env_rows("HP_EMD_ROWS1_R")}, g_rows2{env_rows("HP_EMD_ROWS2_R")}, g_grad2{env_rows("HP_EMD_GRAD2_R") == 4 ? 0 : env_rows("HP_EMD_GRAD2_R")};
 
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(256) void emd_init_kernel(Ctx c, float multiL, floa
 // exactly +0 (exp2 of less than -152): its terms are exact zeros in every phase (approxmatch.cu:86-87,131-132,185-189) and a sweep
 // that leaves them out produces the same sums.  Skipping is only possible for whole (wave, pipeline stage) units, so both sets are
 // put in an order in which 64 consecutive rows and 8 consecutive candidates are spatially compact: along the Hilbert curve of a
-// 128^3 grid over the set's bounding box — consecutive cells of that curve are always neighbours, so ANY run of consecutive points
+// 16^3 grid over the set's bounding box — consecutive cells of that curve are always neighbours, so ANY run of consecutive points
 // is compact, not only the aligned ones (Morton order jumps).  Decidable from the bounding boxes of a (64-row tile, 8-candidate
 // block) unit at the first four levels, uniform clouds: 80 / 70 / 47 / 6 % of the units (Morton 69 / 59 / 33 / 3 %; a k-d order —
 // median splits, 85 / 76 / 54 / 10 % — needs eight segment sorts instead of one and costs more than it saves:
@@ -206,10 +207,9 @@ __global__ __launch_bounds__(256) void emd_init_kernel(Ctx c, float multiL, floa
 // order is another summation order of the same sums (oracle on re-ordered inputs: cost within 3e-7,
 // tools/study/emd_order_sensitivity.py), and the gradient sweeps write through the permutation, so callers see their own order.
 //
-// One workgroup per (cloud, set): keys (Hilbert index | point index) are sorted by a bitonic network in LDS, three compare
-// distances per round trip (8 keys per thread in registers).  Points past the count carry the largest key and stay at the tail.
-// Then the same workgroup writes everything emd_init_kernel writes, in the new order, plus the permutation and the block / tile
-// bounding boxes.
+// One workgroup per (cloud, set): a counting sort by Hilbert cell in LDS (histogram, scan, scatter; the points of a cell in index
+// order, so the order is a pure function of the input).  Then the same workgroup writes everything emd_init_kernel writes, in the
+// new order, plus the permutation and the block / tile bounding boxes.
 // ------------------------------------------------------------------------------------------------
 constexpr int kOrderThreads = 1024;   // 16 waves for the load / key / output phases; the sort network runs on the first P2/8 threads
 constexpr float kFar = 1e18f;     // an empty box: min = +kFar, max = -kFar (its gap to anything squares to 1e36 > any radius)
@@ -250,21 +250,14 @@ __device__ __forceinline__ uint32_t hilbert3(uint32_t x0, uint32_t x1, uint32_t 
     x2 ^= t;
     return (spread3(x0) << 2) | (spread3(x1) << 1) | spread3(x2);
 }
-__device__ __forceinline__ void cmp_up(uint32_t& a, uint32_t& b) {
-    const uint32_t lo = min(a, b), hi = max(a, b);
-    a = lo;
-    b = hi;
-}
-__device__ __forceinline__ void cmp_swap(uint32_t& a, uint32_t& b, bool asc) {
-    const uint32_t lo = min(a, b), hi = max(a, b);
-    a = asc ? lo : hi;
-    b = asc ? hi : lo;
-}
+constexpr int kHilbertBits = 4;                        // 16^3 cells: finer grids do not make 8-point runs more compact (emd_cull_hilbert.py)
+constexpr int kCells = 1 << (3 * kHilbertBits);
 
 __global__ __launch_bounds__(kOrderThreads) void emd_order_kernel(Ctx c, float multiL, float multiR, int logpL, int logpR) {
     extern __shared__ float smem[];
     __shared__ float red[6][kOrderThreads / 64];
-    __shared__ float gb[6], gscale[3];
+    __shared__ float gb[3], gscale[3];
+    __shared__ uint32_t wsum[kOrderThreads / 64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const bool left = blockIdx.x == 0;
     const int cloud = blockIdx.y;
@@ -274,8 +267,11 @@ __global__ __launch_bounds__(kOrderThreads) void emd_order_kernel(Ctx c, float m
     float* X = smem;
     float* Y = X + P2;
     float* Z = Y + P2;
-    uint32_t* key = reinterpret_cast<uint32_t*>(Z + P2);
-    float* box0 = reinterpret_cast<float*>(key + P2);   // NP/8 block boxes [lo xyz | hi xyz] (the output phase)
+    uint32_t* hist = reinterpret_cast<uint32_t*>(Z + P2);            // per cell: count -> start -> end of its slot range
+    uint16_t* cell = reinterpret_cast<uint16_t*>(hist + kCells);     // per point
+    uint16_t* tmp = cell + P2;                                       // slot -> point, arrival order inside a cell
+    uint16_t* key = tmp + P2;                                        // position -> point (the order)
+    float* box0 = reinterpret_cast<float*>(hist);   // NP/8 block boxes [lo xyz | hi xyz] (the output phase; the histogram is dead by then)
 
     // the points and their bounding box
     float mn[3] = {kFar, kFar, kFar}, mx[3] = {-kFar, -kFar, -kFar};
@@ -292,7 +288,9 @@ __global__ __launch_bounds__(kOrderThreads) void emd_order_kernel(Ctx c, float m
         X[i] = x;
         Y[i] = y;
         Z[i] = z;
+        key[i] = (uint16_t)i;                       // positions past the count keep the identity
     }
+    for (int q = tid; q < kCells; q += kOrderThreads) hist[q] = 0u;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
 #pragma unroll
@@ -306,8 +304,6 @@ __global__ __launch_bounds__(kOrderThreads) void emd_order_kernel(Ctx c, float m
         }
     }
     __syncthreads();
-    const uint32_t imask = (uint32_t)P2 - 1u;
-    const int hb = (32 - logp) / 3;                           // Hilbert bits per axis (7 up to 2048 points, 6 at 4096)
     if (tid < 3) {
         float lo = red[tid][0], hi = red[3 + tid][0];
         for (int w = 1; w < kOrderThreads / 64; ++w) {
@@ -315,90 +311,57 @@ __global__ __launch_bounds__(kOrderThreads) void emd_order_kernel(Ctx c, float m
             hi = fmaxf(hi, red[3 + tid][w]);
         }
         gb[tid] = lo;
-        gscale[tid] = hi > lo ? (float)(1 << hb) * 0.9999f / (hi - lo) : 0.f;
+        gscale[tid] = hi > lo ? (float)(1 << kHilbertBits) * 0.9999f / (hi - lo) : 0.f;
     }
     __syncthreads();
-    // keys: Hilbert index of the point's cell | point index; points past the count carry the largest key and stay at the tail
-    for (int i = tid; i < P2; i += kOrderThreads) {
-        uint32_t kk = 0xffffffffu;
-        if (i < cnt) {
-            const uint32_t cm = (1u << hb) - 1u;
-            const uint32_t qx = min((uint32_t)((X[i] - gb[0]) * gscale[0]), cm), qy = min((uint32_t)((Y[i] - gb[1]) * gscale[1]), cm),
-                           qz = min((uint32_t)((Z[i] - gb[2]) * gscale[2]), cm);
-            kk = (hilbert3(qx, qy, qz, hb) << logp) | (uint32_t)i;
-        }
-        key[i] = kk;
+    // A counting sort by Hilbert cell, points of a cell in index order (deterministic: the counts do not depend on the order
+    // the atomics execute in, and the arrival order inside a cell is replaced by the index order below).
+    for (int i = tid; i < cnt; i += kOrderThreads) {
+        const uint32_t cm = (1u << kHilbertBits) - 1u;
+        const uint32_t qx = min((uint32_t)((X[i] - gb[0]) * gscale[0]), cm), qy = min((uint32_t)((Y[i] - gb[1]) * gscale[1]), cm),
+                       qz = min((uint32_t)((Z[i] - gb[2]) * gscale[2]), cm);
+        const uint32_t h = hilbert3(qx, qy, qz, kHilbertBits);
+        cell[i] = (uint16_t)h;
+        atomicAdd(&hist[h], 1u);
     }
     __syncthreads();
-    {
-        const int ls = logp;
-        // bitonic sort, ascending.  Pass 1: every thread sorts its 8 consecutive keys in registers (the merges of size 2, 4, 8), runs
-        // alternately ascending / descending; then the merges of size 16 .. P2, compare distances k/2 .. 1 taken three at a time
-        // (8 keys per thread in registers).  A descending run is an ascending run of the complemented keys.
-        for (int vt = tid; vt < P2 / 8; vt += kOrderThreads) {
-            uint4* p = reinterpret_cast<uint4*>(key + vt * 8);
-            const uint4 q0 = p[0], q1 = p[1];
-            uint32_t v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-            cmp_swap(v[0], v[1], true); cmp_swap(v[2], v[3], false); cmp_swap(v[4], v[5], true); cmp_swap(v[6], v[7], false);
-            cmp_swap(v[0], v[2], true); cmp_swap(v[1], v[3], true); cmp_swap(v[4], v[6], false); cmp_swap(v[5], v[7], false);
-            cmp_swap(v[0], v[1], true); cmp_swap(v[2], v[3], true); cmp_swap(v[4], v[5], false); cmp_swap(v[6], v[7], false);
-            const bool asc = (vt & 1) == 0;
-            cmp_swap(v[0], v[4], asc); cmp_swap(v[1], v[5], asc); cmp_swap(v[2], v[6], asc); cmp_swap(v[3], v[7], asc);
-            cmp_swap(v[0], v[2], asc); cmp_swap(v[1], v[3], asc); cmp_swap(v[4], v[6], asc); cmp_swap(v[5], v[7], asc);
-            cmp_swap(v[0], v[1], asc); cmp_swap(v[2], v[3], asc); cmp_swap(v[4], v[5], asc); cmp_swap(v[6], v[7], asc);
-            p[0] = make_uint4(v[0], v[1], v[2], v[3]);
-            p[1] = make_uint4(v[4], v[5], v[6], v[7]);
+    {   // exclusive scan of the cell counts: kCells / kOrderThreads consecutive cells per thread
+        constexpr int kPer = kCells / kOrderThreads;
+        uint32_t v[kPer], s = 0;
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            v[q] = hist[tid * kPer + q];
+            s += v[q];
         }
-        bool wide = true;                                        // the pending writes may be read by another wave
-        for (int lk = 4; lk <= ls; ++lk) {
-            const int k = 1 << lk;
-            int rem = lk;                                        // distances left in this merge: 2^(rem-1) .. 1
-            while (rem > 0) {
-                const int gg = rem >= 3 ? 3 : rem;              // compare steps in the group (the short group last, at distance 1)
-                const int ljj = rem - gg;                       // log2 of the group's smallest distance
-                const int jj = 1 << ljj;
-                // a wave's 64 threads own 512 consecutive keys while jj <= 64: no other wave reads or writes them
-                const bool wide_now = jj > 64;
-                if (wide || wide_now) __syncthreads();
-                else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                wide = wide_now;
-                for (int vt = tid; vt < P2 / 8; vt += kOrderThreads) {
-                    const int base = ((vt >> ljj) << (ljj + 3)) | (vt & (jj - 1));
-                    const uint32_t flip = (lk == ls || (base & k) == 0) ? 0u : 0xffffffffu;
-                    uint32_t v[8];
-                    if (ljj == 0) {
-                        const uint4* p = reinterpret_cast<const uint4*>(key + base);
-                        const uint4 q0 = p[0], q1 = p[1];
-                        v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
-                    } else {
+        uint32_t inc = s;
 #pragma unroll
-                        for (int a = 0; a < 8; ++a) v[a] = key[base + a * jj];
-                    }
-#pragma unroll
-                    for (int a = 0; a < 8; ++a) v[a] ^= flip;
-                    if (gg == 3) {
-                        cmp_up(v[0], v[4]); cmp_up(v[1], v[5]); cmp_up(v[2], v[6]); cmp_up(v[3], v[7]);
-                    }
-                    if (gg >= 2) {
-                        cmp_up(v[0], v[2]); cmp_up(v[1], v[3]); cmp_up(v[4], v[6]); cmp_up(v[5], v[7]);
-                    }
-                    cmp_up(v[0], v[1]); cmp_up(v[2], v[3]); cmp_up(v[4], v[5]); cmp_up(v[6], v[7]);
-#pragma unroll
-                    for (int a = 0; a < 8; ++a) v[a] ^= flip;
-                    if (ljj == 0) {
-                        uint4* p = reinterpret_cast<uint4*>(key + base);
-                        p[0] = make_uint4(v[0], v[1], v[2], v[3]);
-                        p[1] = make_uint4(v[4], v[5], v[6], v[7]);
-                    } else {
-#pragma unroll
-                        for (int a = 0; a < 8; ++a) key[base + a * jj] = v[a];
-                    }
-                }
-                rem -= gg;
-            }
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
         }
+        if (lane == 63) wsum[wid] = inc;
         __syncthreads();
+        uint32_t base = 0;
+        for (int w = 0; w < wid; ++w) base += wsum[w];
+        uint32_t run = base + inc - s;
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            hist[tid * kPer + q] = run;
+            run += v[q];
+        }
     }
+    __syncthreads();
+    for (int i = tid; i < cnt; i += kOrderThreads) tmp[atomicAdd(&hist[cell[i]], 1u)] = (uint16_t)i;    // hist[h]: start -> end
+    __syncthreads();
+    for (int i = tid; i < cnt; i += kOrderThreads) {
+        const uint32_t h = cell[i];
+        const uint32_t s0 = h ? hist[h - 1] : 0u, s1 = hist[h];      // the cell's slots (the previous cell's end .. its own)
+        uint32_t rank = 0;
+        for (uint32_t q = s0; q < s1; ++q) rank += tmp[q] < (uint16_t)i ? 1u : 0u;
+        key[s0 + rank] = (uint16_t)i;
+    }
+    __syncthreads();
+    const uint32_t imask = 0xffffu;
 
     // ---- outputs (what emd_init_kernel writes, in the new order) ----
     int* perm = reinterpret_cast<int*>(ws + (left ? c.permL : c.permR));
@@ -690,8 +653,9 @@ __global__ __launch_bounds__(kThreads) void emd_rows2_kernel(Ctx c, int lev, flo
 
 // ------------------------------------------------------------------------------------------------
 // Culling sweeps (records in k-d order).  Same rows, same candidates, same arithmetic per (row, candidate) as emd_rows1_kernel /
-// emd_rows2_kernel; the candidate set of a wave is cut into blocks of 8 (one pipeline stage), block g belongs to candidate range
-// (g mod kParts) — interleaved, so that the blocks near a row tile spread over the four waves —, and a (64-row tile, block) unit is
+// emd_rows2_kernel; the candidate set is cut into blocks of 8 (one pipeline stage), block g belongs to the workgroup's wave
+// (g mod P) — interleaved, so that the blocks near a row tile spread over the P = 4 waves (8 or 16 waves per row tile were tried for
+// the sparse levels and lost: 1.18 -> 1.22 / 1.30 ms per call) —, and a (64-row tile, block) unit is
 // evaluated only if the two bounding boxes are closer than the level's underflow radius.  Every skipped term is an exact zero
 // (exp2 of less than -152; fma(0, w, acc) == acc), so a row's sum is the sum over its surviving blocks in ascending order — the
 // reference's sum with its zero terms left out.  The decision is taken per 64-row tile whatever R is: every rows-per-lane
@@ -714,9 +678,9 @@ __device__ __forceinline__ void load_tile_box(const float* tb, int NT, int t, fl
     }
 }
 
-template <bool DO3, bool DO1, int R>
-__global__ __launch_bounds__(kThreads) void emd_rows1_cull_kernel(Ctx c, int lev1, float l2e3, float l2e1, float thr3, float thr1) {
-    __shared__ float part3[kParts][kRowsPerWg * R], part1[kParts][kRowsPerWg * R];
+template <bool DO3, bool DO1, int R, int P>
+__global__ __launch_bounds__(64 * P) void emd_rows1_cull_kernel(Ctx c, int lev1, float l2e3, float l2e1, float thr3, float thr1) {
+    __shared__ float part3[P][kRowsPerWg * R], part1[P][kRowsPerWg * R];
     const int cloud = blockIdx.y;
     const int lrow = threadIdx.x % kRowsPerWg;
     const int part = __builtin_amdgcn_readfirstlane(threadIdx.x / kRowsPerWg);   // wave-uniform
@@ -747,7 +711,7 @@ __global__ __launch_bounds__(kThreads) void emd_rows1_cull_kernel(Ctx c, int lev
         load_tile_box(ws + c.tileL, c.NP / kTile, blockIdx.x * R + r, tlo[r], thi[r]);
     }
     const f2 l3 = splat(l2e3), l1 = splat(l2e1);
-    const int NB = c.MP / kBlk, nblk = NB / kParts;          // blocks of the set, blocks of this wave's range (g = i * kParts + part)
+    const int NB = c.MP / kBlk, nblk = (NB + P - 1) / P;     // blocks of the set, blocks of this wave's range (g = i * P + part)
     const float* bb = ws + c.blkR;
     const float* prec = ws + c.prp;
     const float* wrec = ws + c.rr;
@@ -759,8 +723,8 @@ __global__ __launch_bounds__(kThreads) void emd_rows1_cull_kernel(Ctx c, int lev
         unsigned long long mask1[R], mask3[R], any = 0ull;
         {
             const int i = ch + lane;
-            const bool valid = i < nblk;
-            const int g = valid ? i * kParts + part : 0;
+            const bool valid = i * P + part < NB;
+            const int g = valid ? i * P + part : 0;
             const float cx0 = bb[g], cy0 = bb[NB + g], cz0 = bb[2 * NB + g], cx1 = bb[3 * NB + g], cy1 = bb[4 * NB + g], cz1 = bb[5 * NB + g];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -812,7 +776,7 @@ __global__ __launch_bounds__(kThreads) void emd_rows1_cull_kernel(Ctx c, int lev
         int ia = __builtin_ctzll(any), ib = 0;
         any &= any - 1ull;
         {
-            const long g = (long)(ch + ia) * kParts + part;
+            const long g = (long)(ch + ia) * P + part;
             const float* p = prec + g * (kBlk * 4);
             const float* q = wrec + g * kBlk;
             HP_SLOAD16(a0, p, 0x0);
@@ -825,7 +789,7 @@ __global__ __launch_bounds__(kThreads) void emd_rows1_cull_kernel(Ctx c, int lev
             if (more_b) {
                 ib = __builtin_ctzll(any);
                 any &= any - 1ull;
-                const long g = (long)(ch + ib) * kParts + part;
+                const long g = (long)(ch + ib) * P + part;
                 const float* p = prec + g * (kBlk * 4);
                 const float* q = wrec + g * kBlk;
                 HP_SLOAD16(b0, p, 0x0);
@@ -840,7 +804,7 @@ __global__ __launch_bounds__(kThreads) void emd_rows1_cull_kernel(Ctx c, int lev
             if (more_a) {
                 ia = __builtin_ctzll(any);
                 any &= any - 1ull;
-                const long g = (long)(ch + ia) * kParts + part;
+                const long g = (long)(ch + ia) * P + part;
                 const float* p = prec + g * (kBlk * 4);
                 const float* q = wrec + g * kBlk;
                 HP_SLOAD16(a0, p, 0x0);
@@ -868,7 +832,7 @@ __global__ __launch_bounds__(kThreads) void emd_rows1_cull_kernel(Ctx c, int lev
         if (!ok[r]) continue;
         float t3 = s3[r], t1 = s1[r];
 #pragma unroll
-        for (int q2 = 1; q2 < kParts; ++q2) {
+        for (int q2 = 1; q2 < P; ++q2) {
             t3 += part3[q2][r * kRowsPerWg + lrow];
             t1 += part1[q2][r * kRowsPerWg + lrow];
         }
@@ -886,9 +850,9 @@ __global__ __launch_bounds__(kThreads) void emd_rows1_cull_kernel(Ctx c, int lev
     }
 }
 
-template <int R>
-__global__ __launch_bounds__(kThreads) void emd_rows2_cull_kernel(Ctx c, int lev, float l2e, float thr) {
-    __shared__ float parts[kParts][kRowsPerWg * R];
+template <int R, int P>
+__global__ __launch_bounds__(64 * P) void emd_rows2_cull_kernel(Ctx c, int lev, float l2e, float thr) {
+    __shared__ float parts[P][kRowsPerWg * R];
     const int cloud = blockIdx.y;
     const int lrow = threadIdx.x % kRowsPerWg;
     const int part = __builtin_amdgcn_readfirstlane(threadIdx.x / kRowsPerWg);
@@ -916,7 +880,7 @@ __global__ __launch_bounds__(kThreads) void emd_rows2_cull_kernel(Ctx c, int lev
         load_tile_box(ws + c.tileR, c.MP / kTile, blockIdx.x * R + r, tlo[r], thi[r]);
     }
     const f2 lv = splat(l2e);
-    const int NB = c.NP / kBlk, nblk = NB / kParts;
+    const int NB = c.NP / kBlk, nblk = (NB + P - 1) / P;
     const float* bb = ws + c.blkL;
     const float* prec = ws + c.plp;
     const int lane = threadIdx.x & 63;
@@ -925,8 +889,8 @@ __global__ __launch_bounds__(kThreads) void emd_rows2_cull_kernel(Ctx c, int lev
         unsigned long long mask[R], any = 0ull;
         {
             const int i = ch + lane;
-            const bool valid = i < nblk;
-            const int g = valid ? i * kParts + part : 0;
+            const bool valid = i * P + part < NB;
+            const int g = valid ? i * P + part : 0;
             const float cx0 = bb[g], cy0 = bb[NB + g], cz0 = bb[2 * NB + g], cx1 = bb[3 * NB + g], cy1 = bb[4 * NB + g], cz1 = bb[5 * NB + g];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -965,7 +929,7 @@ __global__ __launch_bounds__(kThreads) void emd_rows2_cull_kernel(Ctx c, int lev
         int ia = __builtin_ctzll(any), ib = 0;
         any &= any - 1ull;
         {
-            const float* p = prec + ((long)(ch + ia) * kParts + part) * (kBlk * 4);
+            const float* p = prec + ((long)(ch + ia) * P + part) * (kBlk * 4);
             HP_SLOAD16(a0, p, 0x0);
             HP_SLOAD16(a1, p, 0x40);
             asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1));
@@ -975,7 +939,7 @@ __global__ __launch_bounds__(kThreads) void emd_rows2_cull_kernel(Ctx c, int lev
             if (more_b) {
                 ib = __builtin_ctzll(any);
                 any &= any - 1ull;
-                const float* p = prec + ((long)(ch + ib) * kParts + part) * (kBlk * 4);
+                const float* p = prec + ((long)(ch + ib) * P + part) * (kBlk * 4);
                 HP_SLOAD16(b0, p, 0x0);
                 HP_SLOAD16(b1, p, 0x40);
             }
@@ -987,7 +951,7 @@ __global__ __launch_bounds__(kThreads) void emd_rows2_cull_kernel(Ctx c, int lev
             if (more_a) {
                 ia = __builtin_ctzll(any);
                 any &= any - 1ull;
-                const float* p = prec + ((long)(ch + ia) * kParts + part) * (kBlk * 4);
+                const float* p = prec + ((long)(ch + ia) * P + part) * (kBlk * 4);
                 HP_SLOAD16(a0, p, 0x0);
                 HP_SLOAD16(a1, p, 0x40);
             }
@@ -1010,7 +974,7 @@ __global__ __launch_bounds__(kThreads) void emd_rows2_cull_kernel(Ctx c, int lev
         if (!ok[r]) continue;
         float a = acc[r];
 #pragma unroll
-        for (int q2 = 1; q2 < kParts; ++q2) a += parts[q2][r * kRowsPerWg + lrow];
+        for (int q2 = 1; q2 < P; ++q2) a += parts[q2][r * kRowsPerWg + lrow];
         const float rr = remR[l[r]];
         const float sumr = a * rr;
         const float consumption = fminf(rr / (sumr + 1e-9f), 1.0f);
@@ -1324,7 +1288,6 @@ struct LevelChain {
     int rows1_r, rows2_r;
     int cull;                      // > 0: records in k-d order, sweeps of levels < cull skip the units that are exactly zero
     int logpL = 0, logpR = 0;      // log2 of the order kernel's sort sizes
-    int cull_r = 0;                // rows per lane of the culling instances (0: rows1_r / rows2_r)
     dim3 ginit, g1[3], g2[3];      // grids at 1, 2, 4 rows per lane
 
     static int log2_ceil64(int x) {
@@ -1368,21 +1331,19 @@ struct LevelChain {
         const int f1 = g_rows1.load(std::memory_order_relaxed), f2 = g_rows2.load(std::memory_order_relaxed);
         rows1_r = f1 ? f1 : pick(n, 2);
         rows2_r = f2 ? f2 : pick(m, 4);
-        cull_r = g_cull_rows.load(std::memory_order_relaxed);
     }
 
     // phase 3 of level lev3 (D3) merged with phase 1 of level lev1 (D1)
     template <bool D3, bool D1>
     void rows1(int lev3, int lev1) const {
         const float l2e3 = D3 ? level_l2e(lev3) : 0.f, l2e1 = D1 ? level_l2e(lev1) : 0.f;
-        int i = rows1_r == 4 ? 2 : rows1_r == 2 ? 1 : 0;
-        if (cull > 0 && (D3 ? lev3 : lev1) < cull) {     // (lev3 < lev1: the launch culls if its finer level does)
+        const int i = rows1_r == 4 ? 2 : rows1_r == 2 ? 1 : 0;
+        // (lev3 < lev1.  A launch whose phase-1 level is past the culling levels visits every block anyway, and then the plain
+        // kernel's straight pipeline is faster than skipping half of the phase-3 terms: measured)
+        const int clev = D1 ? lev1 : lev3;
+        if (cull > 0 && clev < cull) {
             const float t3 = D3 ? radius2(lev3) : 0.f, t1 = D1 ? radius2(lev1) : 0.f;
-            const int cr = cull_r ? cull_r : rows1_r;
-            i = cr == 4 ? 2 : cr == 2 ? 1 : 0;
-            if (cr == 4) hipLaunchKernelGGL((emd_rows1_cull_kernel<D3, D1, 4>), g1[i], dim3(kThreads), 0, stream, c, lev1, l2e3, l2e1, t3, t1);
-            else if (cr == 2) hipLaunchKernelGGL((emd_rows1_cull_kernel<D3, D1, 2>), g1[i], dim3(kThreads), 0, stream, c, lev1, l2e3, l2e1, t3, t1);
-            else hipLaunchKernelGGL((emd_rows1_cull_kernel<D3, D1, 1>), g1[i], dim3(kThreads), 0, stream, c, lev1, l2e3, l2e1, t3, t1);
+            hipLaunchKernelGGL((emd_rows1_cull_kernel<D3, D1, 1, kParts>), g1[0], dim3(kThreads), 0, stream, c, lev1, l2e3, l2e1, t3, t1);
             return;
         }
         if (rows1_r == 4) hipLaunchKernelGGL((emd_rows1_kernel<D3, D1, 4>), g1[i], dim3(kThreads), 0, stream, c, lev1, l2e3, l2e1);
@@ -1390,14 +1351,10 @@ struct LevelChain {
         else hipLaunchKernelGGL((emd_rows1_kernel<D3, D1, 1>), g1[i], dim3(kThreads), 0, stream, c, lev1, l2e3, l2e1);
     }
     void rows2(int lev) const {
-        int i = rows2_r == 4 ? 2 : rows2_r == 2 ? 1 : 0;
+        const int i = rows2_r == 4 ? 2 : rows2_r == 2 ? 1 : 0;
         if (cull > 0 && lev < cull) {
             const float t = radius2(lev);
-            const int cr = cull_r ? cull_r : rows2_r;
-            i = cr == 4 ? 2 : cr == 2 ? 1 : 0;
-            if (cr == 4) hipLaunchKernelGGL(emd_rows2_cull_kernel<4>, g2[i], dim3(kThreads), 0, stream, c, lev, level_l2e(lev), t);
-            else if (cr == 2) hipLaunchKernelGGL(emd_rows2_cull_kernel<2>, g2[i], dim3(kThreads), 0, stream, c, lev, level_l2e(lev), t);
-            else hipLaunchKernelGGL(emd_rows2_cull_kernel<1>, g2[i], dim3(kThreads), 0, stream, c, lev, level_l2e(lev), t);
+            hipLaunchKernelGGL((emd_rows2_cull_kernel<1, kParts>), g2[0], dim3(kThreads), 0, stream, c, lev, level_l2e(lev), t);
             return;
         }
         if (rows2_r == 4) hipLaunchKernelGGL(emd_rows2_kernel<4>, g2[i], dim3(kThreads), 0, stream, c, lev, level_l2e(lev));
@@ -1409,7 +1366,7 @@ struct LevelChain {
         if (s == 0) {
             if (cull > 0) {
                 const int lp = std::max(logpL, logpR);
-                const size_t lds = (size_t)19 << lp;    // 16 bytes per point (x, y, z, key) + P2/8 block boxes of 24 bytes
+                const size_t lds = ((size_t)18 << lp) + kCells * 4;    // per point x, y, z + cell, slot, order (u16); the cell histogram
                 if (lds > 48 * 1024)
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(emd_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 hipLaunchKernelGGL(emd_order_kernel, dim3(2, b), dim3(kOrderThreads), lds, stream, c, multiL, multiR, logpL, logpR);
@@ -1550,7 +1507,7 @@ HP_API int hp_emd_set_cull(int levels) {
 
 // hp_emd_forward* as two chains of half the clouds on two streams (2, default) or as one chain (1); returns the previous setting.
 HP_API int hp_emd_set_chains(int chains) {
-    HP_CHECK_ARG(chains == 1 || chains == 2);
+    HP_CHECK_ARG(chains >= 1 && chains <= kMaxChains);
     return g_chains.exchange(chains);
 }
 
@@ -1685,22 +1642,33 @@ int emd_final_sweep(Ctx c, int b, float* partials, float* cost, float* grad1, fl
 // The second stream is the library's own, one per device, created on first use (non-blocking, high priority: its own hardware
 // queue).  HP_EMD_CHAINS=1 / hp_emd_set_chains(1): one chain (rounds 1-4).
 
-hipStream_t second_chain_stream() {
-    std::mutex& mu = g_s2_mu;
-    std::map<int, hipStream_t>& streams = g_s2_streams;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = streams.find(dev);
-    if (it != streams.end()) return it->second;
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // (numerically lowest = highest priority)
-    hipStream_t s = nullptr;
-    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) != hipSuccess) {
+// The library's own stream number `i` (1..kMaxChains-1) on the device `stream` belongs to (the null stream: the current device).
+// Created on first use on THAT device — the calling thread's current device may be another one — non-blocking, high
+// priority: its own hardware queue.
+hipStream_t chain_stream(hipStream_t stream, int i) {
+    int cur = 0, dev = 0;
+    if (hipGetDevice(&cur) != hipSuccess) return nullptr;
+    dev = cur;
+    if (stream && hipStreamGetDevice(stream, &dev) != hipSuccess) {
         (void)hipGetLastError();
-        s = nullptr;
+        dev = cur;
     }
-    streams[dev] = s;
+    std::lock_guard<std::mutex> lock(g_s2_mu);
+    auto it = g_s2_streams.find(dev * kMaxChains + i);
+    if (it != g_s2_streams.end()) return it->second;
+    hipStream_t s = nullptr;
+    if (dev == cur || hipSetDevice(dev) == hipSuccess) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // (numerically lowest = highest priority)
+        if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) != hipSuccess) {
+            (void)hipGetLastError();
+            s = nullptr;
+        }
+        if (dev != cur) (void)hipSetDevice(cur);
+    } else {
+        (void)hipGetLastError();
+    }
+    g_s2_streams[dev * kMaxChains + i] = s;
     return s;
 }
 
@@ -1709,42 +1677,53 @@ int emd_forward_impl(int b, int n, int m, const float* xyz1, const float* xyz2, 
     HP_CHECK_ARG(b >= 0 && n > 0 && m > 0);
     if (b == 0) return 0;
     HP_CHECK_ARG(xyz1 && xyz2 && temp && ws && partials && cost && b <= 65535);
-    // two chains only where a half still fills the chip (>= 2 waves per SIMD at one row per lane) and a capture is not in
+    // several chains only where each part still fills the chip (>= 2 waves per SIMD at one row per lane) and a capture is not in
     // progress on the caller's stream (a captured call stays on the stream it was captured on)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(stream, &cap);
-    const int h = b / 2;
-    const bool split = g_chains.load(std::memory_order_relaxed) == 2 && cap == hipStreamCaptureStatusNone &&
-                       (long)h * ((std::min(n, m) + kRowsPerWg - 1) / kRowsPerWg) * (kThreads / 64) >= 2048;
-    hipStream_t s2 = split ? second_chain_stream() : nullptr;
-    if (!s2) return emd_forward_chain(b, n, m, xyz1, xyz2, temp, ws, partials, cost, grad1, grad2, acc_scale, stream, after);
-    const WsLayout L = ws_layout(n, m);
-    int rc = hp_order_streams(stream, s2);                                       // the inputs are ready on `stream`
-    if (rc) return rc;
-    const int cull = g_cull.load(std::memory_order_relaxed);
-    const LevelChain c0(h, n, m, xyz1, xyz2, temp, ws, stream, false, cull);
-    const LevelChain c1(b - h, n, m, xyz1 + (long)h * n * 3, xyz2 + (long)h * m * 3, temp + (long)h * (n + m) * 2, ws + (long)h * L.per_cloud,
-                        s2, false, cull);
-    for (int st = 0; st < LevelChain::kSteps; ++st) {      // alternately: both streams are fed at the same pace
-        c0.step(st);
-        c1.step(st);
+    int nch = cap == hipStreamCaptureStatusNone ? g_chains.load(std::memory_order_relaxed) : 1;
+    while (nch > 1 && (long)(b / nch) * ((std::min(n, m) + kRowsPerWg - 1) / kRowsPerWg) * (kThreads / 64) < 2048) --nch;
+    hipStream_t st[kMaxChains] = {stream};
+    for (int i = 1; i < nch; ++i) {
+        st[i] = chain_stream(stream, i);
+        if (!st[i]) nch = 1;
     }
+    if (nch <= 1) return emd_forward_chain(b, n, m, xyz1, xyz2, temp, ws, partials, cost, grad1, grad2, acc_scale, stream, after);
+    const WsLayout L = ws_layout(n, m);
+    const int cull = g_cull.load(std::memory_order_relaxed);
+    int rc = 0;
+    for (int i = 1; i < nch && !rc; ++i) rc = hp_order_streams(stream, st[i]);      // the inputs are ready on `stream`
+    if (rc) return rc;      // (nothing is enqueued on the library's streams yet)
+    std::vector<LevelChain> ch;
+    ch.reserve(nch);
+    for (int i = 0; i < nch; ++i) {
+        const int c0 = (int)((long)b * i / nch), c1 = (int)((long)b * (i + 1) / nch);
+        ch.emplace_back(c1 - c0, n, m, xyz1 + (long)c0 * n * 3, xyz2 + (long)c0 * m * 3, temp + (long)c0 * (n + m) * 2, ws + (long)c0 * L.per_cloud,
+                        st[i], false, cull);
+    }
+    for (int s = 0; s < LevelChain::kSteps; ++s)      // alternately: all streams are fed at the same pace
+        for (int i = 0; i < nch; ++i) ch[i].step(s);
     rc = (int)hipGetLastError();
-    if (rc) return rc;
-    // the final sweep is ONE launch over all clouds again, behind both chains: it is a single long launch (nothing follows it that
+    // the final sweep is ONE launch over all clouds again, behind every chain: it is a single long launch (nothing follows it that
     // could cover its tail), and as two half-size launches the second ran its last ~110 us alone on a half-empty chip
     // (173 + 284 us in the trace against 288 for the whole batch)
     // ... and behind `after` (the stream that wrote the gradient the sweep accumulates into).  Every wait costs the waiting stream a
-    // bubble of several microseconds even when the event has long fired, so the caller's stream gets ONE: `after` is joined into
-    // the second chain's stream first (nothing is queued there behind its chain), and that stream into the caller's.
+    // bubble of several microseconds even when the event has long fired, so the caller's stream gets as few as possible: `after` is
+    // joined into the last chain's stream first (nothing is queued there behind its chain), the library's streams into one
+    // another, and the last one into the caller's.
     const bool ext = after && after != stream && acc_scale != 0.f;
-    if (ext) {
-        rc = hp_order_streams(after, s2);
-        if (rc) return rc;
+    if (!rc && ext) rc = hp_order_streams(after, st[nch - 1]);
+    // On a failure the library's streams are still joined into the caller's (best effort): the caller only knows `stream` and may
+    // free or reuse temp / ws / the inputs behind it.
+    for (int i = 1; i + 1 < nch; ++i) {
+        const int r2 = hp_order_streams(st[i], st[i + 1]);
+        if (!rc) rc = r2;
     }
-    rc = hp_order_streams(s2, stream);
+    const int r3 = hp_order_streams(st[nch - 1], stream);
+    if (!rc) rc = r3;
     if (rc) return rc;
-    return emd_final_sweep(c0.c, b, partials, cost, grad1, grad2, acc_scale, stream, ext ? nullptr : after);
+    Ctx call = ch[0].c;      // the whole batch: chain 0 starts at cloud 0
+    return emd_final_sweep(call, b, partials, cost, grad1, grad2, acc_scale, stream, ext ? nullptr : after);
 }
 
 }  // namespace

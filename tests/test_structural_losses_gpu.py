@@ -6,6 +6,8 @@ EMD parity is otherwise unpinned, see oracle/structural_losses_ref.c), per-entry
 `match`, 5e-5 + 1e-3 relative on the cost gradients; every rows-per-lane instance of the EMD sweeps is forced
 through hp_emd_set_rows_per_lane and compared with the oracle and, bit for bit, with the others.
 """
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -229,20 +231,36 @@ def test_match_cost_autograd_function(oracle_lib):
 
 
 def test_fused_match_cost_equals_materialised_path(backend):
-    """match_cost (match-free: hp_emd_forward/backward) against ApproxMatch -> MatchCost -> MatchCostGrad on the GPU:
-    same match entries evaluated in the same order -> cost and grad1 agree to fp32 rounding of the final sums."""
+    """match_cost (match-free: hp_emd_forward/backward) against ApproxMatch -> MatchCost -> MatchCostGrad on the GPU.
+    With the level sweeps in the caller's order (hp_emd_set_cull(0)) the two evaluate the same match entries in the same order:
+    cost and gradients agree to fp32 rounding of the final sums.  By default (round 6) the match-free path sweeps in Hilbert order
+    and leaves the exactly-zero units out — another summation order of the same sums, which the auction amplifies like any other
+    fp32 re-ordering: the cost stays inside 2e-6, the gradients inside the envelope every two fp32 evaluations of the algorithm
+    share (_assert_grad_close)."""
+    from hyperpocket_amd._lib import load_library
     from hyperpocket_amd.utils.pytorch_structural_losses.match_cost import match_cost
-    for b, n, m in [(3, 257, 257), (2, 500, 250), (2, 100, 300)]:
-        a, c = _clouds(31 + n, b, n, m)
-        A, C = _dev(a).requires_grad_(True), _dev(c).requires_grad_(True)
-        cost = match_cost(A, C)
-        cost.sum().backward()
-        match, _ = backend.ApproxMatch(_dev(a), _dev(c))
-        cost2 = backend.MatchCost(_dev(a), _dev(c), match)
-        g1, g2 = backend.MatchCostGrad(_dev(a), _dev(c), match)
-        np.testing.assert_allclose(cost.detach().cpu().numpy(), cost2.cpu().numpy(), rtol=2e-6)
-        np.testing.assert_allclose(A.grad.cpu().numpy(), g1.cpu().numpy(), rtol=1e-5, atol=1e-6)
-        np.testing.assert_allclose(C.grad.cpu().numpy(), g2.cpu().numpy(), rtol=1e-4, atol=2e-6)
+    lib = load_library()
+    default = lib.hp_emd_set_cull(0)
+    try:
+        for cull in (0, default):
+            lib.hp_emd_set_cull(cull)
+            for b, n, m in [(3, 257, 257), (2, 500, 250), (2, 100, 300)]:
+                a, c = _clouds(31 + n, b, n, m)
+                A, C = _dev(a).requires_grad_(True), _dev(c).requires_grad_(True)
+                cost = match_cost(A, C)
+                cost.sum().backward()
+                match, _ = backend.ApproxMatch(_dev(a), _dev(c))
+                cost2 = backend.MatchCost(_dev(a), _dev(c), match)
+                g1, g2 = backend.MatchCostGrad(_dev(a), _dev(c), match)
+                np.testing.assert_allclose(cost.detach().cpu().numpy(), cost2.cpu().numpy(), rtol=2e-6)
+                if cull == 0:
+                    np.testing.assert_allclose(A.grad.cpu().numpy(), g1.cpu().numpy(), rtol=1e-5, atol=1e-6)
+                    np.testing.assert_allclose(C.grad.cpu().numpy(), g2.cpu().numpy(), rtol=1e-4, atol=2e-6)
+                else:
+                    _assert_grad_close(A.grad.cpu().numpy(), g1.cpu().numpy(), "grad1, Hilbert-ordered sweeps vs the caller's order")
+                    _assert_grad_close(C.grad.cpu().numpy(), g2.cpu().numpy(), "grad2, Hilbert-ordered sweeps vs the caller's order")
+    finally:
+        lib.hp_emd_set_cull(default)
     # only the second argument needs a gradient in training (match_cost(gt, rec))
     A, C = _dev(a), _dev(c).requires_grad_(True)
     match_cost(A, C).sum().backward()
@@ -438,6 +456,116 @@ def test_emd_two_chains_equal_one_chain(b, n, m):
                         assert torch.equal(gx, gy)
     finally:
         lib.hp_emd_set_chains(prev)
+
+
+def _emd_order_tables(ws, b, n, m):
+    """What emd_order_kernel leaves in the workspace (emd.hip ws_layout): per cloud the two permutations (position -> caller's
+    index), the 8-candidate block boxes and the flag."""
+    from hyperpocket_amd._lib import load_library
+    per = load_library().hp_approxmatch_workspace_floats(1, n, m)
+    w = ws.view(b, per)
+    NP, MP = (n + 63) // 64 * 64, (m + 63) // 64 * 64
+    off = (NP + 8) * 4 + (MP + 8) * 4 + (MP + 8) + (NP + 8) * 16 + (MP + 8) * 16
+    permL = w[:, off:off + NP].view(torch.int32)[:, :n].cpu().numpy()
+    permR = w[:, off + NP:off + NP + MP].view(torch.int32)[:, :m].cpu().numpy()
+    blkL = w[:, off + NP + MP:off + NP + MP + 6 * (NP // 8)].reshape(b, 6, NP // 8).cpu().numpy()
+    flag = w[:, per - 16].cpu().numpy()
+    return permL, permR, blkL, flag
+
+
+def _emd_forward_ws(a, c):
+    """hp_emd_forward (grad2 only) keeping the workspace."""
+    from hyperpocket_amd._lib import call, current_stream, load_library
+    lib = load_library()
+    lib.hp_emd_partials_floats.restype = ctypes.c_long
+    A, C = _dev(a), _dev(c)
+    b, n, m = A.shape[0], A.shape[1], C.shape[1]
+    f32 = dict(device=A.device, dtype=torch.float32)
+    temp = torch.empty((b, 2 * (n + m)), **f32)
+    ws = torch.zeros((lib.hp_approxmatch_workspace_floats(b, n, m),), **f32)
+    part = torch.empty((lib.hp_emd_partials_floats(b, n, m),), **f32)
+    cost = torch.empty((b,), **f32)
+    g2 = torch.full((b, m, 3), float("nan"), **f32)
+    call("hp_emd_forward", b, n, m, A, C, temp, ws, part, cost, None, g2, current_stream(A.device))
+    torch.cuda.synchronize()
+    return cost, g2, ws
+
+
+@pytest.mark.parametrize("b,n,m", [(3, 96, 96), (2, 200, 330), (5, 330, 200), (2, 1000, 2048), (3, 2048, 2048), (2, 3000, 4096)])
+def test_emd_order_kernel_leaves_a_permutation_and_tight_boxes(b, n, m):
+    """emd_order_kernel (round 6): the Hilbert order of either set is a permutation of the caller's indices (ragged sizes, sizes
+    that are not powers of two, the 4096-point limit), the block boxes are the exact bounding boxes of the 8 points they cover,
+    the order is a pure function of the input (two runs: identical tables), and consecutive blocks are compact: the mean block
+    diagonal is far below a random block's."""
+    from hyperpocket_amd._lib import load_library
+    lib = load_library()
+    a, c = _clouds(900 + n, b, n, m)
+    prev = lib.hp_emd_set_cull(3)
+    try:
+        _, _, ws = _emd_forward_ws(a, c)
+        permL, permR, blkL, flag = _emd_order_tables(ws, b, n, m)
+        _, _, ws2 = _emd_forward_ws(a, c)
+        assert torch.equal(ws, ws2)                                      # deterministic, records and tables alike
+        lib.hp_emd_set_cull(0)
+        _, _, ws0 = _emd_forward_ws(a, c)
+        assert (_emd_order_tables(ws0, b, n, m)[3] == 0).all()           # the caller's order: flag off
+    finally:
+        lib.hp_emd_set_cull(prev)
+    assert (flag == 1).all()
+    for i in range(b):
+        assert np.array_equal(np.sort(permL[i]), np.arange(n)) and np.array_equal(np.sort(permR[i]), np.arange(m))
+        pts = a[i][permL[i]]
+        full = n // 8
+        blocks = pts[:full * 8].reshape(full, 8, 3)
+        np.testing.assert_array_equal(blkL[i, :3, :full].T, blocks.min(1))
+        np.testing.assert_array_equal(blkL[i, 3:, :full].T, blocks.max(1))
+        diag = np.linalg.norm(blocks.max(1) - blocks.min(1), axis=1).mean()
+        rand = a[i][:full * 8].reshape(full, 8, 3)
+        assert diag < (0.5 if n >= 512 else 0.75) * np.linalg.norm(rand.max(1) - rand.min(1), axis=1).mean()
+
+
+@pytest.mark.parametrize("b,n,m", [(3, 96, 96), (2, 200, 330), (5, 330, 200), (66, 2048, 2048)])
+def test_emd_culling_sweeps_equal_the_full_sweeps_in_the_same_order(b, n, m):
+    """The culling sweeps leave out (64-row tile, 8-candidate block) units whose every exponential is exactly zero.  With the
+    records in the same (Hilbert) order, culling NO level (hp_emd_set_cull(k), k levels culled) and culling 1, 3, 4 or all 9
+    levels must therefore give the same cost and gradients up to the candidate-range grouping of the partial sums (the culling
+    kernels interleave the candidate blocks over a workgroup's four waves, the plain ones give each wave a contiguous quarter):
+    cost within 2e-6, gradients inside the fp32 re-ordering envelope.  And against the caller's order (cull 0): the same bars.
+    Clouds in the +-0.5 cube: at levels -16384 .. -1024 most units are beyond the underflow radius, so the skipping is exercised."""
+    from hyperpocket_amd._lib import load_library
+    lib = load_library()
+    a, c = _clouds(77 + n, b, n, m)
+    prev = lib.hp_emd_set_cull(0)
+    try:
+        base = _emd_forward(a, c, True, True)
+        for k in (1, 3, 4, 9):
+            lib.hp_emd_set_cull(k)
+            got = _emd_forward(a, c, True, True)
+            assert all(torch.isfinite(t).all() for t in got)
+            np.testing.assert_allclose(got[0].cpu().numpy(), base[0].cpu().numpy(), rtol=2e-6, err_msg=f"cost, cull={k}")
+            _assert_grad_close(got[1].cpu().numpy(), base[1].cpu().numpy(), f"grad1, cull={k} vs caller's order")
+            _assert_grad_close(got[2].cpu().numpy(), base[2].cpu().numpy(), f"grad2, cull={k} vs caller's order")
+            again = _emd_forward(a, c, True, True)
+            assert all(torch.equal(x, y) for x, y in zip(got, again)), f"cull={k}: not reproducible"
+    finally:
+        lib.hp_emd_set_cull(prev)
+
+
+def test_emd_culling_far_apart_sets_and_degenerate_clouds(oracle_lib):
+    """Edge cases of the ordering / culling path against the oracle: (1) the two sets far apart (every unit beyond every culling
+    radius: all masks empty, ratioL = remainL / 1e-9 as in approxmatch.cu:89-93), (2) every point of a set identical (one Hilbert
+    cell, degenerate boxes), (3) a set with n = 1."""
+    r = np.random.RandomState(3)
+    a = (r.rand(2, 300, 3).astype(np.float32) - 0.5)
+    far = a[:, :200] + np.float32(3.0)
+    same = np.repeat(r.rand(2, 1, 3).astype(np.float32), 256, 1)
+    for x, y in ((a, far), (same, a), (a, same), (a[:, :1], a)):
+        cost, g1, g2 = _emd_forward(x, y, True, True)
+        om, _ = oracle_lib.approxmatch(x, y)
+        np.testing.assert_allclose(cost.cpu().numpy(), oracle_lib.matchcost(x, y, om), rtol=1e-5, atol=1e-6)
+        o1, o2 = oracle_lib.matchcostgrad(x, y, om)
+        _assert_grad_close(g1.cpu().numpy(), o1)
+        _assert_grad_close(g2.cpu().numpy(), o2)
 
 
 def test_emd_final_sweep_derived_exponentials_vs_all_nine_from_hardware(oracle_lib):
