@@ -310,11 +310,13 @@ class TrainEngine:
         self.flat.clear_param_grads()
         device = gt.device
         # who takes the heads' weight gradient of THIS step's hypernetwork node (state of this model, not of the process)
+        if self.fused is not None:
+            # (a pass left over from a failed step must not be cleared silently — and it raises BEFORE the hooks below are
+            #  installed on the model: a raise behind them would leave a later backward outside the engine routed into this object)
+            self.fused.check()
         exch = self.shard if (self.exchange and self.shard is not None) else (self.fused if not self.exchange else None)
         model.hyper_network._heads_exchange = exch
         model._after_encoder_tails = self.fused if (self.fused is not None and self.fused.stream is not None) else None
-        if self.fused is not None:
-            self.fused.check()     # (a pass left over from a failed step must not be cleared silently)
         # The step's own random draws — eps of the VAE encoder, the decoder's input points — depend on nothing: the PREVIOUS step
         # drew them on the side stream, beside its EMD sweeps (_predraw), so that the two small launches (4 + 8 us with their
         # gaps) are not on the compute stream between the optimiser and the first conv launch / in front of the decoder.  The
@@ -475,10 +477,22 @@ class TrainEngine:
             grads += [g_lv.view_as(logvar), g_mu.view_as(mu)]
         return roots, grads, out
 
+    def discard_predrawn(self):
+        """Drop the draws made ahead for the next step.  The pre-draw advances torch's device generator and the point sampler's
+        counter ONE step early: an RNG state saved between two steps is one draw ahead of the parameters saved with it, so a run
+        resumed from such a checkpoint re-draws what was already drawn unless the saver calls this first and the resumed run
+        starts with HP_PREDRAW=0 semantics for its first step — or, simpler, saves and restores RNG state right after
+        construction / this call.  (Bit-identical resume needs the same pre-draw setting in both runs.)"""
+        self._next_eps = self._next_points = None
+
     def _predraw(self, dev):
         """Next step's random draws (called on the side stream).  Only what this step did NOT get injected, and only for the
         shapes of this step (another batch size or epoch next time: the pre-drawn tensors are ignored and drawn again then —
-        the device sampler's counter has moved, which shifts its sequence but not its law)."""
+        the device sampler's counter has moved, which shifts its sequence but not its law).
+        The two tensors are the one exception to "what outlives the side-stream section is allocated on the compute stream"
+        (_losses_and_gradients): they are allocated on the side stream, consumed on the compute stream in the next step (behind
+        the join that ends this section) and freed there; their blocks return to the SIDE stream's pool, whose every later user
+        first does side.wait_stream(compute) — that wait is what makes the reuse safe without record_stream()."""
         model = self.model
         (B, N, epoch), eps_given, pts_given = self._predraw_for
         auto_eps = getattr(self, "_auto_eps", None)

@@ -23,10 +23,10 @@ CFG = {
 }
 
 
-def _data():
+def _data(n=4):
     g = torch.Generator().manual_seed(3)
-    ex, mi = torch.rand(4, 128, 3, generator=g) - 0.5, torch.rand(4, 128, 3, generator=g) - 0.5
-    pts, eps = torch.rand(4, 256, 3, generator=g) * 2 - 1, torch.randn(4, 128, generator=g)
+    ex, mi = torch.rand(n, 128, 3, generator=g) - 0.5, torch.rand(n, 128, 3, generator=g) - 0.5
+    pts, eps = torch.rand(n, 256, 3, generator=g) * 2 - 1, torch.randn(n, 128, generator=g)
     return ex, mi, torch.cat([ex, mi], 1), pts, eps
 
 
@@ -39,7 +39,7 @@ def _build():
     return m.cuda()
 
 
-def _worker(rank, world, port, out, shard):
+def _worker(rank, world, port, out, shard, nclouds=4):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "3d-point-clouds-autocomplete_amd")):
         if p not in sys.path:
@@ -49,14 +49,15 @@ def _worker(rank, world, port, out, shard):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     model = _build()
-    if rank == 1:                      # replicas must start from rank 0's weights: perturb, the engine's broadcast repairs it
+    if rank != 0:                      # replicas must start from rank 0's weights: perturb, the engine's broadcast repairs it
         with torch.no_grad():
             for p in model.parameters():
                 p.add_(0.01)
     eng = TrainEngine(model, emd_coef=0.05, shard_heads=shard)
     assert (eng.shard is not None) == shard
-    ex, mi, gt, pts, eps = (t.cuda() for t in _data())
-    sl = slice(rank * 2, rank * 2 + 2)
+    ex, mi, gt, pts, eps = (t.cuda() for t in _data(nclouds))
+    per = nclouds // world
+    sl = slice(rank * per, rank * per + per)
     for _ in range(2):
         res = eng.step(ex[sl].contiguous(), mi[sl].contiguous(), gt[sl].contiguous(), 7, points=pts[sl].contiguous(),
                        eps_noise=eps[sl].contiguous())
@@ -70,10 +71,14 @@ def _worker(rank, world, port, out, shard):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("shard", [True, False], ids=["sharded-heads", "all-reduce"])
-def test_two_rank_engine_matches_single_process_global_batch(shard):
+@pytest.mark.parametrize("shard,world,nclouds", [(True, 2, 4), (False, 2, 4), (True, 8, 8)],
+                         ids=["sharded-heads", "all-reduce", "eight-ranks-sharded-heads"])
+def test_two_rank_engine_matches_single_process_global_batch(shard, world, nclouds):
     """Both exchanges of the heads' gradient: `shard` = ranks all-gather d theta / t5, each updates its row slice of the
-    heads and the updated rows are all-gathered (HeadsShard); otherwise the flat gradient is all-reduced."""
+    heads and the updated rows are all-gathered (HeadsShard); otherwise the flat gradient is all-reduced.
+    `eight-ranks`: the node's world size — 8 ranks (all on cuda:0, gloo), one cloud each: the W = 8 row sharding of the
+    19011 head rows (2377-row slices, the last one ragged: the 19016-row padding), the deferred gathers and the small-bucket
+    all-reduce run end to end with the real kernels, against one process stepping on the 8 clouds."""
     from hyperpocket_amd import ops
     from hyperpocket_amd.core.engine import TrainEngine
     s = socket.socket()
@@ -83,11 +88,11 @@ def test_two_rank_engine_matches_single_process_global_batch(shard):
     ctx = mp.get_context("spawn")
     import tempfile
     out = os.path.join(tempfile.mkdtemp(), "rank0_params.pt")
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, shard)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out, shard, nclouds)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(timeout=600)
+        p.join(timeout=900)
         assert p.exitcode == 0
     saved = torch.load(out)
     got, got_opt = saved["params"], saved["opt"]
@@ -95,7 +100,7 @@ def test_two_rank_engine_matches_single_process_global_batch(shard):
     model = _build()
     eng = TrainEngine(model, emd_coef=0.05)
     try:
-        ex, mi, gt, pts, eps = (t.cuda() for t in _data())
+        ex, mi, gt, pts, eps = (t.cuda() for t in _data(nclouds))
         for _ in range(2):
             eng.step(ex, mi, gt, 7, points=pts, eps_noise=eps)
         eng.finish_pending()
