@@ -1001,12 +1001,16 @@ __global__ __launch_bounds__(64 * P) void emd_rows2_cull_kernel(Ctx c, int lev, 
 // as well and the auction amplified it past the parity bars; here nothing is downstream of the value: M moves by
 // <= 3.5e-7 relative, cost and gradients by less (tests: the cost error map's bars are unchanged, and the exact form stays
 // selectable: hp_emd_set_final_derive).
-template <bool ROW_IS_L, bool DERIVE>
+// SKIP (round 6): the first SKIP levels' exponentials are known to be exactly zero for this (row tile, candidate block) — the
+// boxes are further apart than those levels' underflow radius (the culling test of the level sweeps; a derived value is the
+// fourth power of a hardware exponential below 2^-38, i.e. below 2^-152: zero as well) — and their terms are left out.
+template <bool ROW_IS_L, bool DERIVE, int SKIP = 0>
 __device__ __forceinline__ f2 match_entry2(f2 d, const float (&row)[kLevels], const f32x16& lo, const f32x16& hi) {
     f2 acc = splat(0.f);
     f2 ev[kLevels];
 #pragma unroll
     for (int lev = kLevels - 1; lev >= 0; --lev) {
+        if (lev < SKIP) continue;      // (an odd level is the source of the even level below it only: nothing kept derives from a skipped one)
         if (!DERIVE || lev == kLevels - 1 || (lev & 1)) {
             ev[lev] = exp2_2(splat(level_l2e(lev)) * d);
         } else {
@@ -1015,7 +1019,7 @@ __device__ __forceinline__ f2 match_entry2(f2 d, const float (&row)[kLevels], co
         }
     }
 #pragma unroll
-    for (int lev = 0; lev < kLevels; ++lev) {
+    for (int lev = SKIP; lev < kLevels; ++lev) {
         const f2 e = ev[lev];
         const f2 cr = FINC(lo, hi, 3 + lev);
         // the level's term rides on an fma into the running sum (one rounding instead of the reference's two, i.e. a
@@ -1154,16 +1158,20 @@ __global__ __launch_bounds__(kThreads) void emd_cost_grad1_kernel(Ctx c, float* 
 // same sweep also yields the cost (sum over the same pairs, owned by l instead of k), so a training step that only
 // needs d cost / d xyz2 evaluates the match entries once.
 template <bool WITH_COST, int R, bool DERIVE>
-__global__ __launch_bounds__(kThreads) void emd_grad2_kernel(Ctx c, float* __restrict__ grad2, float* __restrict__ partials) {
+__global__ __launch_bounds__(kThreads) void emd_grad2_kernel(Ctx c, float* __restrict__ grad2, float* __restrict__ partials, float thr1, float thr2) {
     __shared__ float red[kThreads / 64];
     __shared__ float parts[kParts][4][kRowsPerWg * R];
     const int cloud = blockIdx.y;
     const int lrow = threadIdx.x % kRowsPerWg;
     const int part = __builtin_amdgcn_readfirstlane(threadIdx.x / kRowsPerWg);
     const float* ws = c.ws + (long)cloud * c.per_cloud;
+    // thr1 / thr2: the underflow radii of levels 1 and 2 (3e38: that tier is off).  Only with the records in Hilbert order: the
+    // boxes exist and mean something.
+    const bool tiers = ws[c.flag] != 0.f && thr1 < 1e38f;
     int l[R];
     bool ok[R];
     float rR[R][kLevels];
+    float tlo[R][3], thi[R][3];
     f2 qx2[R], qy2[R], qz2[R], sx2[R], sy2[R], sz2[R], cost2[R];   // sums: even / odd candidates (see emd_rows1_kernel)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -1177,13 +1185,18 @@ __global__ __launch_bounds__(kThreads) void emd_grad2_kernel(Ctx c, float* __res
         qy2[r] = splat(qy);
         qz2[r] = splat(qz);
         sx2[r] = sy2[r] = sz2[r] = cost2[r] = splat(0.f);
+        if (tiers) load_tile_box(ws + c.tileR, c.MP / kTile, blockIdx.x * R + r, tlo[r], thi[r]);
     }
-    auto work = [&](const f32x16& lo, const f32x16& hi) {
+    unsigned long long far1[R], far2[R];      // per candidate block of the current chunk: beyond level 1's radius / level 2's
+    auto work = [&](const f32x16& lo, const f32x16& hi, int bi) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const f2 ex = qx2[r] - FINC(lo, hi, 0), ey = qy2[r] - FINC(lo, hi, 1), ez = qz2[r] - FINC(lo, hi, 2);
             const f2 d2 = sqdist2(ex, ey, ez);
-            const f2 mv = match_entry2<false, DERIVE>(d2, rR[r], lo, hi);
+            f2 mv;
+            if ((far2[r] >> bi) & 1ull) mv = match_entry2<false, DERIVE, 3>(d2, rR[r], lo, hi);
+            else if ((far1[r] >> bi) & 1ull) mv = match_entry2<false, DERIVE, 2>(d2, rR[r], lo, hi);
+            else mv = match_entry2<false, DERIVE, 0>(d2, rR[r], lo, hi);
             const f2 w = mv * f2{__builtin_amdgcn_rsqf(fmaxf(d2.x, 1e-20f)), __builtin_amdgcn_rsqf(fmaxf(d2.y, 1e-20f))};
             if (WITH_COST)
                 cost2[r] = DERIVE ? __builtin_elementwise_fma(w, d2, cost2[r])      // (M / sqrt(d)) * d, see emd_cost_grad1_kernel
@@ -1193,27 +1206,49 @@ __global__ __launch_bounds__(kThreads) void emd_grad2_kernel(Ctx c, float* __res
             sz2[r] = __builtin_elementwise_fma(ez, w, sz2[r]);
         }
     };
-    const int cand = c.NP / kParts;
+    const int cand = c.NP / kParts, nblk = cand / kBlk;      // this wave's candidates: blocks [part * nblk, (part + 1) * nblk) of set1
+    const int NB = c.NP / kBlk;
+    const float* bb = ws + c.blkL;
+    const int lane = threadIdx.x & 63;
     const float* p = ws + c.flp + (long)part * cand * 16;
     f32x16 a0, a1, b0, b1;
     HP_SLOAD16(a0, p, 0x0);
     HP_SLOAD16(a1, p, 0x40);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1));
-    for (int k = 0; k < cand; k += 4) {
-        p += 32;
-        HP_SLOAD16(b0, p, 0x0);
-        HP_SLOAD16(b1, p, 0x40);
-        HP_PIN();
-        work(a0, a1);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1), "+v"(sx2[0]), "+v"(sy2[0]), "+v"(sz2[0]), "+v"(cost2[0]),
-                     "+v"(sx2[R - 1]), "+v"(sy2[R - 1]), "+v"(sz2[R - 1]), "+v"(cost2[R - 1]));
-        p += 32;
-        HP_SLOAD16(a0, p, 0x0);
-        HP_SLOAD16(a1, p, 0x40);
-        HP_PIN();
-        work(b0, b1);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(sx2[0]), "+v"(sy2[0]), "+v"(sz2[0]), "+v"(cost2[0]),
-                     "+v"(sx2[R - 1]), "+v"(sy2[R - 1]), "+v"(sz2[R - 1]), "+v"(cost2[R - 1]));
+    for (int ch = 0; ch < nblk; ch += 64) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) far1[r] = far2[r] = 0ull;
+        if (tiers) {
+            const bool valid = ch + lane < nblk;
+            const int g = valid ? part * nblk + ch + lane : 0;
+            const float cx0 = bb[g], cy0 = bb[NB + g], cz0 = bb[2 * NB + g], cx1 = bb[3 * NB + g], cy1 = bb[4 * NB + g], cz1 = bb[5 * NB + g];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float g2 = box_gap2(tlo[r], thi[r], cx0, cy0, cz0, cx1, cy1, cz1);
+                far1[r] = __ballot(valid && g2 > thr1);
+                far2[r] = __ballot(valid && g2 > thr2);
+            }
+        }
+        const int nb = min(64, nblk - ch);
+        for (int bi = 0; bi < nb; ++bi) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {      // a block = 8 candidates = four pair records
+                p += 32;
+                HP_SLOAD16(b0, p, 0x0);
+                HP_SLOAD16(b1, p, 0x40);
+                HP_PIN();
+                work(a0, a1, bi);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1), "+v"(sx2[0]), "+v"(sy2[0]), "+v"(sz2[0]), "+v"(cost2[0]),
+                             "+v"(sx2[R - 1]), "+v"(sy2[R - 1]), "+v"(sz2[R - 1]), "+v"(cost2[R - 1]));
+                p += 32;
+                HP_SLOAD16(a0, p, 0x0);
+                HP_SLOAD16(a1, p, 0x40);
+                HP_PIN();
+                work(b0, b1, bi);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(sx2[0]), "+v"(sy2[0]), "+v"(sz2[0]), "+v"(cost2[0]),
+                             "+v"(sx2[R - 1]), "+v"(sy2[R - 1]), "+v"(sz2[R - 1]), "+v"(cost2[R - 1]));
+            }
+        }
     }
     float sx[R], sy[R], sz[R], cost[R];
 #pragma unroll
@@ -1592,9 +1627,18 @@ int emd_forward_chain(int b, int n, int m, const float* xyz1, const float* xyz2,
     return emd_final_sweep(c, b, partials, cost, grad1, grad2, acc_scale, stream, after);
 }
 // the cost / gradient sweep(s) of one chain behind its level sweeps
+// the final sweep's tiers: underflow radii of levels 1 and 2 where those levels cull (3e38: tier off; HP_EMD_FINAL_TIERS=0: both off)
+void final_tiers(float& thr1, float& thr2) {
+    static const bool on = [] { const char* e = getenv("HP_EMD_FINAL_TIERS"); return !(e && atoi(e) == 0); }();
+    const int cull = on ? g_cull.load(std::memory_order_relaxed) : 0;
+    thr1 = cull > 1 ? 152.f / -level_l2e(1) : 3.0e38f;
+    thr2 = cull > 2 ? 152.f / -level_l2e(2) : 3.0e38f;
+}
 int emd_final_sweep(Ctx c, int b, float* partials, float* cost, float* grad1, float* grad2, float acc_scale, hipStream_t stream,
                     hipStream_t after) {
     const int n = c.n, m = c.m;
+    float thr1, thr2;
+    final_tiers(thr1, thr2);
     int rc = 0;
     c.acc_scale = acc_scale;
     if (after && after != stream) {   // the accumulated-into gradient was written on `after`: order the sweep behind it
@@ -1609,12 +1653,12 @@ int emd_final_sweep(Ctx c, int b, float* partials, float* cost, float* grad1, fl
         // two rows per lane when that still leaves >= 2 waves per SIMD (as in run_levels; -0.01 ms at B=64, N=2048)
         const int gr = genv ? genv : ((long)b * mbr * (kThreads / 64) >= 2048 ? 2 : 1);
         if (gr == 2) {
-            if (derive) hipLaunchKernelGGL((emd_grad2_kernel<true, 2, true>), dim3(mbr, b), dim3(kThreads), 0, stream, c, grad2, partials);
-            else hipLaunchKernelGGL((emd_grad2_kernel<true, 2, false>), dim3(mbr, b), dim3(kThreads), 0, stream, c, grad2, partials);
+            if (derive) hipLaunchKernelGGL((emd_grad2_kernel<true, 2, true>), dim3(mbr, b), dim3(kThreads), 0, stream, c, grad2, partials, thr1, thr2);
+            else hipLaunchKernelGGL((emd_grad2_kernel<true, 2, false>), dim3(mbr, b), dim3(kThreads), 0, stream, c, grad2, partials, thr1, thr2);
             hipLaunchKernelGGL(emd_cost_finish_kernel, dim3(b), dim3(256), 0, stream, partials, mbr, cost);
         } else {
-            if (derive) hipLaunchKernelGGL((emd_grad2_kernel<true, 1, true>), dim3(mb, b), dim3(kThreads), 0, stream, c, grad2, partials);
-            else hipLaunchKernelGGL((emd_grad2_kernel<true, 1, false>), dim3(mb, b), dim3(kThreads), 0, stream, c, grad2, partials);
+            if (derive) hipLaunchKernelGGL((emd_grad2_kernel<true, 1, true>), dim3(mb, b), dim3(kThreads), 0, stream, c, grad2, partials, thr1, thr2);
+            else hipLaunchKernelGGL((emd_grad2_kernel<true, 1, false>), dim3(mb, b), dim3(kThreads), 0, stream, c, grad2, partials, thr1, thr2);
             hipLaunchKernelGGL(emd_cost_finish_kernel, dim3(b), dim3(256), 0, stream, partials, mb, cost);
         }
         // (the second sweep's partials are unused: cost was already reduced, in stream order, by the finish kernel)
@@ -1736,7 +1780,9 @@ HP_API int hp_emd_backward(int b, int n, int m, const float* xyz1, const float* 
     HP_CHECK_ARG(ws && grad2 && b <= 65535);
     Ctx c = make_ctx(n, m, xyz1, xyz2, nullptr, const_cast<float*>(ws));
     const dim3 grid((m + kRowsPerWg - 1) / kRowsPerWg, b);
-    if (g_final_derive.load(std::memory_order_relaxed)) hipLaunchKernelGGL((emd_grad2_kernel<false, 1, true>), grid, dim3(kThreads), 0, stream, c, grad2, nullptr);
-    else hipLaunchKernelGGL((emd_grad2_kernel<false, 1, false>), grid, dim3(kThreads), 0, stream, c, grad2, nullptr);
+    float thr1, thr2;
+    final_tiers(thr1, thr2);
+    if (g_final_derive.load(std::memory_order_relaxed)) hipLaunchKernelGGL((emd_grad2_kernel<false, 1, true>), grid, dim3(kThreads), 0, stream, c, grad2, nullptr, thr1, thr2);
+    else hipLaunchKernelGGL((emd_grad2_kernel<false, 1, false>), grid, dim3(kThreads), 0, stream, c, grad2, nullptr, thr1, thr2);
     HP_RETURN_LAST_ERROR();
 }
