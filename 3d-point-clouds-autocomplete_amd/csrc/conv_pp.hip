@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256 * WM, 2 / WM) void conv_pp_kernel(const PpParam
         //   G3  A0, B0 <- tile kt+1 (t0, ip0) from the OTHER buffer | DMA(kt+2) part 0 -> this buffer | MFMA(A1, B1, ip1)
         // (Round 4 tried a two-group ping-pong — one wave of a SIMD in an MFMA phase while its partner loads — first: in-kernel
         //  stamps showed the loading wave making no progress beside a back-to-back MFMA stream, even with s_setprio and with
-        //  load phases free of vector-ALU instructions: 93 us per conv5 either way.  DESIGN.md 7b.)
+        //  load phases free of vector-ALU instructions: 93 us per conv5 either way.  docs/DESIGN_HISTORY.md 7b.)
         // k-tile 0 of this tile was issued before the previous tile's epilogue (whose stores are younger: vmcnt(0) waits for them
         // too — they have had the whole epilogue to drain).
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -38,7 +38,7 @@
 #include <vector>
 
 // (Round 3's derived-exponential experiment — e(j) = e(j+1)^4, -0.08 ms per step, fails the parity bars — lives as a patch in
-// tools/micro/emd_derive.patch, not in the shipped library: DESIGN.md 7b.)
+// tools/micro/emd_derive.patch, not in the shipped library: docs/DESIGN_HISTORY.md 7b.)
 
 namespace {
 
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void emd_init_kernel(Ctx c, float multiL, floa
 // is compact, not only the aligned ones (Morton order jumps).  Decidable from the bounding boxes of a (64-row tile, 8-candidate
 // block) unit at the first four levels, uniform clouds: 80 / 70 / 47 / 6 % of the units (Morton 69 / 59 / 33 / 3 %; a k-d order —
 // median splits, 85 / 76 / 54 / 10 % — needs eight segment sorts instead of one and costs more than it saves:
-// tools/study/emd_cull_hilbert.py, DESIGN.md 3.2).  The algorithm is indifferent to the order of either set; a sweep in another
+// tools/study/emd_cull_hilbert.py, DESIGN.md 4).  The algorithm is indifferent to the order of either set; a sweep in another
 // order is another summation order of the same sums (oracle on re-ordered inputs: cost within 3e-7,
 // tools/study/emd_order_sensitivity.py), and the gradient sweeps write through the permutation, so callers see their own order.
 //
@@ -998,7 +998,7 @@ __global__ __launch_bounds__(64 * P) void emd_rows2_cull_kernel(Ctx c, int lev, 
 // 4 apart — l_j * d = 4 * (l_{j+1} * d) bit for bit — so exp2(l_j d) = exp2(l_{j+1} d)^4, and levels 0, 2, 4, 6 are formed as the
 // fourth power (two packed multiplies) of the hardware exponential of levels 1, 3, 5, 7: five v_exp_f32 per pair instead of nine.
 // A derived value carries ~5 ulp (4 x the exponential's + the two squarings') instead of 1.  Round 3 tried this in the LEVEL sweeps
-// as well and the auction amplified it past the parity bars; here nothing is downstream of the value: M moves by
+// as well and the auction amplified it past the parity bars (docs/DESIGN_HISTORY.md 7b); here nothing is downstream of the value: M moves by
 // <= 3.5e-7 relative, cost and gradients by less (tests: the cost error map's bars are unchanged, and the exact form stays
 // selectable: hp_emd_set_final_derive).
 // SKIP (round 6): the first SKIP levels' exponentials are known to be exactly zero for this (row tile, candidate block) — the
@@ -1680,7 +1680,7 @@ int emd_final_sweep(Ctx c, int b, float* partials, float* cost, float* grad1, fl
 // same launches on several times the clouds amortise (tools/emd_launch_bound.py: 1.371 ms at 64 clouds, 1.217 per 64 at 576).
 // So the call runs as TWO chains of half the clouds on two streams: while one chain's launch ramps up or drains, the other's
 // waves hold the vector pipes — what a persistent per-cloud kernel would give, without a flag hand-off and without anything that
-// could wait for a workgroup the dispatcher has not placed.  Per cloud the arithmetic is that of one chain
+// could wait for a workgroup the dispatcher has not placed (docs/DESIGN_HISTORY.md 7b).  Per cloud the arithmetic is that of one chain
 // (the halves may run other rows-per-lane instances, which are bit-identical per row): match-free cost within the partials'
 // regrouping (2e-6, as between instances), gradients identical.  Measured at B = 64, N = 2048: 1.370 -> 1.280 ms per call.
 // The second stream is the library's own, one per device, created on first use (non-blocking, high priority: its own hardware

@@ -22,7 +22,7 @@
 // No atomics, fixed summation orders: run-to-run identical; per row the arithmetic does not depend on how many encoders
 // share the launches.
 //
-// What shaped it (measured, tools/micro/enc_bwd_probe.hip + HP_EB_PROF stamps):
+// What shaped it (measured, tools/micro/enc_bwd_probe.hip + HP_EB_PROF stamps; docs/DESIGN_HISTORY.md §3.5):
 //  * a grid of 16 row blocks per cloud leaves the dead blocks interleaved with the live ones and XCDs 6, 7 without a live
 //    block: 296 us against 168 with the live blocks as the first, contiguous ids;
 //  * hipcc sinks prefetch loads behind the MFMA block that should cover them, and a load inside a branch makes the waitcnt
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(512) void enc_bwd_prep_kernel(const HpEncBwdArgs a)
 // written as zeros (the matrix-core launches run on whole 32-row blocks).
 // Round 5: four W5 rows in flight per wave (HP_EB_GEB, was 8) at four workgroups per CU (98 VGPRs, no spill; was 148 / three):
 // the launch is a chain of dependent memory round trips, occupancy hides them — 125 -> 108 us in the step's trace (the step
-// itself does not move: the region is bandwidth-bound beside the heads' dW + Adam pass).
+// itself does not move: the region is bandwidth-bound beside the heads' dW + Adam pass, docs/DESIGN_HISTORY.md 8).
 #ifndef HP_EB_GOCC
 #define HP_EB_GOCC 4
 #endif

@@ -19,7 +19,7 @@
 // L2s are not coherent with each other, so a barrier needs either agent-scope release/acquire (buffer_wbl2 + buffer_inv:
 // ~11 us per barrier with nothing dirty) or sc1 (memory-side) accesses for everything the phases exchange — then an
 // atomic-free flag barrier costs ~4 us, but the slab re-reads that the per-XCD L2 absorbs for free in separate launches
-// all go to the memory side: 88 us per direction against 68 us as six launches.
+// all go to the memory side: 88 us per direction against 68 us as six launches (docs/DESIGN_HISTORY.md 7b).
 #include "hp_common.h"
 #include "hp_skinny.h"
 #include <algorithm>

@@ -6,7 +6,7 @@
 //   /root/reference/utils/pytorch_structural_losses/approxmatch.cu  :34-357
 //   /root/reference/losses/champfer_loss.py                         :11-35 (fused forward/backward)
 //
-// Design:
+// Design (see docs/DESIGN_HISTORY.md §kernels):
 //  * nn_distance: one launch covers both directions.  A workgroup owns 256*R query points of one
 //    cloud (R points per lane in registers) and sweeps the other set through a 12 KB LDS tile of
 //    candidate groups read as wave-uniform ds_read_b128 broadcasts into packed fp32 ops.  No global

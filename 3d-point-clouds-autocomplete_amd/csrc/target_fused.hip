@@ -730,7 +730,7 @@ bool g_fwd_f16 = [] {
 }();
 
 // (Round 3's f16-pipe backward prototype — 147 us against this kernel's 151, 512 VGPRs and 240 B of scratch — lives as a patch in
-// tools/micro/target_bwd_f16.patch, not in the shipped library: DESIGN.md 7b.)
+// tools/micro/target_bwd_f16.patch, not in the shipped library: docs/DESIGN_HISTORY.md 7b.)
 }  // namespace
 
 // The fused forward's hidden layers on the f16 matrix pipe with split fp32 operands (default) or on the fp32 one (0; also

@@ -477,8 +477,8 @@ def roofline_emd(batch, n):
     fn = lambda: call("hp_emd_forward", batch, n, n, a, c, temp, ws, part, cost, None, g2, st)
     ms = event_time_ms(fn, iters=20, warm=10)
     cull = lib.hp_emd_set_cull(0)
-    try:
-        ms0 = event_time_ms(fn, iters=20, warm=10) if cull else ms
+    try:      # (HP_BENCH_EMD_NO_UNCULL=1: the PMC passes of tools/final_measure.sh profile the shipped call only)
+        ms0 = event_time_ms(fn, iters=20, warm=10) if cull and not os.environ.get("HP_BENCH_EMD_NO_UNCULL") else ms
     finally:
         lib.hp_emd_set_cull(cull)
     fn()

@@ -198,7 +198,7 @@ def test_matchcostgrad_oracle_finite_difference(oracle_lib):
 @pytest.mark.parametrize("b,n,m,seed", [(4, 256, 256, 1), (4, 512, 512, 2), (4, 300, 150, 4), (2, 1024, 1024, 3)])
 def test_approxmatch_oracle_distance_from_fp64_under_every_contraction(oracle_lib, b, n, m, seed):
     """EMD parity is unpinned (no reference build / vectors), and whether nvcc contracted the reference's
-    `w=__expf(d)*buf; suml+=w` into fma is unknowable here.  What is measurable: how far the fp32
+    `w=__expf(d)*buf; suml+=w` into fma is unknowable here (docs/DESIGN_HISTORY.md §7b).  What is measurable: how far the fp32
     restatement sits from the fp64 evaluation of the same nine-level algorithm under EVERY contraction assumption
     (oracle/structural_losses_ref.c `contract` bits).  Finding, asserted here: single match entries differ by ~1e-4
     between any two fp32 evaluations, rarely far more against fp64 (the auction amplifies rounding and clamps flip), while the cost — the scalar north_star gates at

@@ -826,9 +826,9 @@ def test_emd_cost_error_distribution_at_full_size(oracle_lib):
     """The EMD cost north_star gates at 1e-5, MAPPED instead of sampled: hp_emd_forward (the engine's call, B = regime
     size, N = 2048) against the C oracle under the kernels' contraction (3) and the literal source (0) on 208 clouds in four
     regimes.  Asserted: every cloud whose cost carries mass (> 1e-3; a matched cloud's is O(10..1000)) within 1e-5
-    relative (the gate), 99th percentile within 2e-6; the distribution is printed (pytest -s) and quoted in DESIGN.md 2.
+    relative (the gate), 99th percentile within 2e-6; the distribution is printed (pytest -s) and quoted in docs/DESIGN_HISTORY.md 2.
     Measured in round 4 (MI355X): max 7.6e-7, p99 <= 6.4e-7, median 0..1.6e-7 in every regime and under both contractions —
-    at the untrained-network operating point (where DESIGN.md 3.6 once saw 1.16e-5 with another MFMA shape upstream) the 15 of
+    at the untrained-network operating point (where docs/DESIGN_HISTORY.md 3.6 once saw 1.16e-5 with another MFMA shape upstream) the 15 of
     48 clouds that carry mass sit at <= 6.5e-7 with the shipped kernels; the other 33 have cost ~1e-24 (every exponential
     underflows) and are held to an absolute 1e-6."""
     regimes = _emd_regimes()

@@ -6,7 +6,7 @@ finishing alone); a persistent kernel with free hand-offs between the phases wou
 k x 64 clouds amortise those fixed costs over k times the work while every wave runs the identical instruction stream, so
     T(64) - T(64 k) / k
 bounds from above what removing the launch boundaries of the B = 64 call can gain (a real persistent kernel also pays its
-flag hand-offs: ~3-4 us each with agent-scope release / acquire)."""
+flag hand-offs: ~3-4 us each with agent-scope release / acquire, docs/DESIGN_HISTORY.md 7b)."""
 import json
 import os
 import sys

@@ -14,7 +14,7 @@
 // PROTOTYPE (round 3, not part of the library): built into libhyperpocket_hip.so for one measurement by copying it to csrc/ —
 // tools/bench_xwt.py: conv5 (65536 x 512 x 512) 323 us = 106 TFLOP/s against gemm.hip's 277 us = 124; conv4 171 vs 162 us;
 // conv3 54.3 vs 54.5 us; conv2 22.3 vs 20.9 us — bit-identical outputs, but two 256-VGPR waves per SIMD behind one barrier per
-// k-tile do not beat six 80-VGPR waves per SIMD.  DESIGN.md 7b.
+// k-tile do not beat six 80-VGPR waves per SIMD.  docs/DESIGN_HISTORY.md 7b.
 #include "../../3d-point-clouds-autocomplete_amd/csrc/hp_common.h"
 #include "../../3d-point-clouds-autocomplete_amd/csrc/hp_gemm.h"
 #include <cstdlib>

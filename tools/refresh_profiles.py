@@ -6,7 +6,8 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 F = os.path.join(R, "gpurun_out", "final")
 P = os.path.join(R, "profiles")
 py = sys.executable
-RD = os.environ.get("HP_ROUND", "r05")
+RD = os.environ.get("HP_ROUND", "r06")
+PRE = int(os.environ.get("HP_PRECONDITION", "400"))      # bench.py --precondition: untimed steps in every step trace
 RN = RD.lstrip("r0")
 
 
@@ -37,20 +38,20 @@ for src, dst in (("bench_n1.json", "bench_n1.json"), ("bench_chamfer.json", "ben
 summ = os.path.join(R, "tools", "summarize_profile.py")
 subprocess.check_call([py, summ, os.path.join(F, "step"), os.path.join(P, f"{RD}_step_kernel_stats.md"),
                        f"Round {RN} — full step: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-extras "
-                       "--no-cpu-baseline (B=64, Chamfer+EMD; 7 engine steps, nothing else in the trace)", "7"])
+                       "--no-cpu-baseline (B=64, Chamfer+EMD; " + str(PRE) + " pre-conditioning + 7 engine steps in the trace)", str(PRE + 7)])
 subprocess.check_call([py, summ, os.path.join(F, "roof"), os.path.join(P, f"{RD}_roofline_kernel_stats.md"),
                        f"Round {RN} — roofline launch alone: rocprofv3 --kernel-trace --stats -- python3 bench.py --roofline-minimal "
                        "(encoder conv5: M=65536, N=K=512; 200 warm-up + 100 timed launches, back to back)", "1"])
 subprocess.check_call([py, summ, os.path.join(F, "roof_emd"), os.path.join(P, f"{RD}_roofline_emd_kernel_stats.md"),
                        f"Round {RN} — the `roofline` object's command alone: rocprofv3 --kernel-trace --stats -- python3 bench.py --roofline-emd-only "
-                       "(hp_emd_forward at B=64, n=m=2048: 10 warm-up + 20 timed calls; per call 1 init + 9 emd_rows1 + 9 emd_rows2 + 1 emd_grad2 + 1 finish)", "30"])
+                       "(hp_emd_forward at B=64, n=m=2048, noisy-copy regime: 10 + 20 calls with the culling sweeps, 10 + 20 with hp_emd_set_cull(0), 1 for the culled share; per shipped call 2 emd_order + 12 culling + 24 plain level launches + 1 emd_grad2 + 1 finish)", "61"])
 subprocess.check_call([py, summ, os.path.join(F, "stress"), os.path.join(P, f"{RD}_chamfer_n8192_kernel_stats.md"),
                        f"Round {RN} — BASELINE configs[4] per-GPU shape: rocprofv3 --kernel-trace --stats -- python3 bench.py --workload "
                        "chamfer-stress --steps 5 --warmup 2 --no-extras (B=64, N=8192, Chamfer forward+backward; 7 steps)", "7"])
 pm = os.path.join(R, "tools", "pmc_summary.py")
-subprocess.check_call([py, pm, os.path.join(P, f"{RD}_pmc_step_kernels.md"),
-                       f"Round {RN} — PMC view of every kernel of the step (bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline)",
-                       os.path.join(F, "step_pmc_FETCH_SIZE"), os.path.join(F, "step_pmc_WRITE_SIZE"), os.path.join(F, "step_pmc_BUSY")])
+subprocess.check_call([py, pm, os.path.join(P, f"{RD}_pmc_emd_kernels.md"),
+                       f"Round {RN} — PMC view of the kernels of hp_emd_forward (bench.py --roofline-emd-only, shipped sweeps: 31 calls at B=64, n=m=2048, noisy-copy regime)",
+                       os.path.join(F, "emd_pmc_FETCH_SIZE"), os.path.join(F, "emd_pmc_WRITE_SIZE"), os.path.join(F, "emd_pmc_BUSY")])
 subprocess.check_call([py, pm, os.path.join(P, f"{RD}_pmc_chamfer_n8192.md"),
                        f"Round {RN} — PMC view of the Chamfer stress kernels (bench.py --workload chamfer-stress, B=64, N=8192)",
                        os.path.join(F, "stress_pmc_FETCH_SIZE"), os.path.join(F, "stress_pmc_WRITE_SIZE"), os.path.join(F, "stress_pmc_BUSY")])
@@ -101,8 +102,8 @@ out = {
 json.dump(out, open(os.path.join(P, f"{RD}_pmc_chamfer_n8192.json"), "w"), indent=1)
 
 # ---- EMD family: HBM bytes per hp_emd_forward call + measured VALU issue cycles against the model
-fes, wrs, bus = per_kernel("step_pmc_FETCH_SIZE"), per_kernel("step_pmc_WRITE_SIZE"), per_kernel("step_pmc_BUSY")
-steps = 4
+fes, wrs, bus = per_kernel("emd_pmc_FETCH_SIZE"), per_kernel("emd_pmc_WRITE_SIZE"), per_kernel("emd_pmc_BUSY")
+steps = 31      # hp_emd_forward calls in `bench.py --roofline-emd-only` with HP_BENCH_EMD_NO_UNCULL=1
 tot_bytes = tot_valu = tot_us = tot_gui = 0.0
 rows = []
 for kname in sorted(k for k in bus if k.startswith("void emd_") or k.startswith("emd_")):
@@ -117,10 +118,13 @@ for kname in sorted(k for k in bus if k.startswith("void emd_") or k.startswith(
                  "valu_issue_busy_frac": round(c["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * c["GRBM_GUI_ACTIVE"] / 8), 4),
                  "hbm_MB_per_launch": round((fes[kname][0]["FETCH_SIZE"] * 2048 + wrs[kname][0]["WRITE_SIZE"] * 1024) / 1e6, 2)})
 mp = os.path.join(P, f"{RD}_emd_issue_model.json")
+if not os.path.exists(mp):      # the static instruction-stream model of the un-culled sweeps: carried over from the round that made it
+    prev = sorted(glob.glob(os.path.join(P, "r[0-9][0-9]_emd_issue_model.json")))[-1]
+    shutil.copy(prev, mp)
 model = json.load(open(mp))
 model["hbm_bytes_per_call"] = int(tot_bytes)
-model["pmc"] = {"command": "rocprofv3 --kernel-trace --pmc ... -- python3 bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline "
-                           "(tools/final_measure.sh); per hp_emd_forward call = per step",
+model["pmc"] = {"command": "rocprofv3 --kernel-trace --pmc ... -- python3 bench.py --roofline-emd-only (HP_BENCH_EMD_NO_UNCULL=1; "
+                           "tools/final_measure.sh): the shipped call (Hilbert order + culling sweeps), noisy-copy regime, 31 calls",
                 "SQ_ACTIVE_INST_VALU_x4_cycles_per_call": int(tot_valu),
                 "model_over_measured_valu_cycles": round(model["issue_cycles_per_call"] / tot_valu, 4),
                 "valu_issue_busy_frac_of_kernel_time": round(tot_valu / (1024 * tot_gui), 4),
