@@ -1779,10 +1779,20 @@ HP_API int hp_emd_backward(int b, int n, int m, const float* xyz1, const float* 
     if (b == 0) return 0;
     HP_CHECK_ARG(ws && grad2 && b <= 65535);
     Ctx c = make_ctx(n, m, xyz1, xyz2, nullptr, const_cast<float*>(ws));
-    const dim3 grid((m + kRowsPerWg - 1) / kRowsPerWg, b);
     float thr1, thr2;
     final_tiers(thr1, thr2);
-    if (g_final_derive.load(std::memory_order_relaxed)) hipLaunchKernelGGL((emd_grad2_kernel<false, 1, true>), grid, dim3(kThreads), 0, stream, c, grad2, nullptr, thr1, thr2);
-    else hipLaunchKernelGGL((emd_grad2_kernel<false, 1, false>), grid, dim3(kThreads), 0, stream, c, grad2, nullptr, thr1, thr2);
+    // rows per lane as in the forward's final sweep (round 6: one row per lane at B = 64, N = 2048 took 465 us against ~250 at two)
+    const int genv = g_grad2.load(std::memory_order_relaxed);
+    const int mbr = (m + 2 * kRowsPerWg - 1) / (2 * kRowsPerWg);
+    const bool two = (genv ? genv : ((long)b * mbr * (kThreads / 64) >= 2048 ? 2 : 1)) == 2;
+    const dim3 grid(two ? mbr : (m + kRowsPerWg - 1) / kRowsPerWg, b);
+    const bool derive = g_final_derive.load(std::memory_order_relaxed) != 0;
+    if (two) {
+        if (derive) hipLaunchKernelGGL((emd_grad2_kernel<false, 2, true>), grid, dim3(kThreads), 0, stream, c, grad2, nullptr, thr1, thr2);
+        else hipLaunchKernelGGL((emd_grad2_kernel<false, 2, false>), grid, dim3(kThreads), 0, stream, c, grad2, nullptr, thr1, thr2);
+    } else {
+        if (derive) hipLaunchKernelGGL((emd_grad2_kernel<false, 1, true>), grid, dim3(kThreads), 0, stream, c, grad2, nullptr, thr1, thr2);
+        else hipLaunchKernelGGL((emd_grad2_kernel<false, 1, false>), grid, dim3(kThreads), 0, stream, c, grad2, nullptr, thr1, thr2);
+    }
     HP_RETURN_LAST_ERROR();
 }

@@ -524,14 +524,15 @@ def test_emd_order_kernel_leaves_a_permutation_and_tight_boxes(b, n, m):
         assert diag < (0.5 if n >= 512 else 0.75) * np.linalg.norm(rand.max(1) - rand.min(1), axis=1).mean()
 
 
-@pytest.mark.parametrize("b,n,m", [(3, 96, 96), (2, 200, 330), (5, 330, 200), (66, 2048, 2048)])
+@pytest.mark.parametrize("b,n,m", [(3, 96, 96), (2, 200, 330), (5, 330, 200), (66, 2048, 2048), (1, 4100, 64)])
 def test_emd_culling_sweeps_equal_the_full_sweeps_in_the_same_order(b, n, m):
     """The culling sweeps leave out (64-row tile, 8-candidate block) units whose every exponential is exactly zero.  With the
     records in the same (Hilbert) order, culling NO level (hp_emd_set_cull(k), k levels culled) and culling 1, 3, 4 or all 9
     levels must therefore give the same cost and gradients up to the candidate-range grouping of the partial sums (the culling
     kernels interleave the candidate blocks over a workgroup's four waves, the plain ones give each wave a contiguous quarter):
     cost within 2e-6, gradients inside the fp32 re-ordering envelope.  And against the caller's order (cull 0): the same bars.
-    Clouds in the +-0.5 cube: at levels -16384 .. -1024 most units are beyond the underflow radius, so the skipping is exercised."""
+    Clouds in the +-0.5 cube: at levels -16384 .. -1024 most units are beyond the underflow radius, so the skipping is exercised.
+    (1, 4100, 64): a set past the ordering kernel's 4096-point limit — the call falls back to the caller's order, all settings alike.)"""
     from hyperpocket_amd._lib import load_library
     lib = load_library()
     a, c = _clouds(77 + n, b, n, m)
