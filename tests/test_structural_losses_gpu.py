@@ -569,6 +569,37 @@ def test_emd_culling_far_apart_sets_and_degenerate_clouds(oracle_lib):
         _assert_grad_close(g2.cpu().numpy(), o2)
 
 
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: a stream of cuda:1 while cuda:0 is the current device")
+def test_emd_forward_on_a_stream_of_another_device_than_the_current_one():
+    """hp_emd_forward runs half of the clouds on a stream the library owns.  That stream must live on the device of the
+    CALLER'S stream, not on whatever device the calling thread has current (emd.hip chain_stream): tensors and stream on cuda:1,
+    current device cuda:0, result equal to the same call made with cuda:1 current."""
+    from hyperpocket_amd._lib import call, load_library
+    lib = load_library()
+    lib.hp_emd_partials_floats.restype = ctypes.c_long
+    a, c = _clouds(12, 66, 2048, 2048)
+    dev = torch.device("cuda", 1)
+    A, C = torch.from_numpy(a).to(dev), torch.from_numpy(c).to(dev)
+    b, n, m = A.shape[0], A.shape[1], C.shape[1]
+    f32 = dict(device=dev, dtype=torch.float32)
+
+    def run():
+        temp = torch.empty((b, 2 * (n + m)), **f32)
+        ws = torch.empty((lib.hp_approxmatch_workspace_floats(b, n, m),), **f32)
+        part = torch.empty((lib.hp_emd_partials_floats(b, n, m),), **f32)
+        cost, g2 = torch.empty((b,), **f32), torch.empty((b, m, 3), **f32)
+        st = torch.cuda.Stream(device=dev)
+        st.wait_stream(torch.cuda.current_stream(dev))
+        call("hp_emd_forward", b, n, m, A, C, temp, ws, part, cost, None, g2, ctypes.c_void_p(st.cuda_stream))
+        st.synchronize()
+        return cost.cpu(), g2.cpu()
+    with torch.cuda.device(1):
+        want = run()
+    with torch.cuda.device(0):
+        got = run()
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+
+
 def test_emd_final_sweep_derived_exponentials_vs_all_nine_from_hardware(oracle_lib):
     """The match-free cost / gradient sweep forms four of its nine per-level exponentials as the fourth power of their
     neighbour's (emd.hip match_entry2<., DERIVE>; default on).  Against the same sweep with all nine from v_exp_f32, over the
