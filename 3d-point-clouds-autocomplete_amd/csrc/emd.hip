@@ -652,14 +652,15 @@ __global__ __launch_bounds__(kThreads) void emd_rows2_kernel(Ctx c, int lev, flo
 }
 
 // ------------------------------------------------------------------------------------------------
-// Culling sweeps (records in k-d order).  Same rows, same candidates, same arithmetic per (row, candidate) as emd_rows1_kernel /
+// Culling sweeps (records in Hilbert order).  Same rows, same candidates, same arithmetic per (row, candidate) as emd_rows1_kernel /
 // emd_rows2_kernel; the candidate set is cut into blocks of 8 (one pipeline stage), block g belongs to the workgroup's wave
 // (g mod P) — interleaved, so that the blocks near a row tile spread over the P = 4 waves (8 or 16 waves per row tile were tried for
 // the sparse levels and lost: 1.18 -> 1.22 / 1.30 ms per call) —, and a (64-row tile, block) unit is
 // evaluated only if the two bounding boxes are closer than the level's underflow radius.  Every skipped term is an exact zero
 // (exp2 of less than -152; fma(0, w, acc) == acc), so a row's sum is the sum over its surviving blocks in ascending order — the
-// reference's sum with its zero terms left out.  The decision is taken per 64-row tile whatever R is: every rows-per-lane
-// instance still evaluates each row identically.  Lane i of a wave tests block i of its range (one ballot per row tile), the
+// reference's sum with its zero terms left out.  The culling instances run ONE row per lane whatever the plain kernels' rows per
+// lane are (a launch is one round of workgroups and lasts as long as its slowest CU: finer workgroups balance; R = 2: +3 % per
+// call), so a row's result does not depend on hp_emd_set_rows_per_lane.  Lane i of a wave tests block i of its range (one ballot per row tile), the
 // surviving blocks are walked with s_ff1 on the masks, their records prefetched one block ahead on the scalar path as before.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float box_gap2(const float (&tlo)[3], const float (&thi)[3], float cx0, float cy0, float cz0, float cx1, float cy1,
@@ -1534,7 +1535,7 @@ HP_API int hp_emd_set_final_derive(int on) { return g_final_derive.exchange(on !
 
 // hp_emd_forward* / hp_emd_forward_acc: the records in k-d order and the sweeps of the first `levels` annealing levels skipping the
 // (64-row tile, 8-candidate block) units whose terms are all exactly zero (emd_order_kernel, emd_rows*_cull_kernel); 0 = the
-// caller's point order, every unit evaluated (rounds 1-5).  Default 4 (HP_EMD_CULL at load time).  Returns the previous setting.
+// caller's point order, every unit evaluated (rounds 1-5).  Default 3 (HP_EMD_CULL at load time).  Returns the previous setting.
 HP_API int hp_emd_set_cull(int levels) {
     HP_CHECK_ARG(levels >= 0 && levels <= kLevels);
     return g_cull.exchange(levels);

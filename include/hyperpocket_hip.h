@@ -84,7 +84,7 @@ int hp_emd_set_chains(int chains);
  * exponentials is exactly +0 in fp32, so each skipped term of approxmatch.cu:86-87,131-132,185-189 is an exact zero).  Results:
  * the sums of the caller's order with their zero terms left out, accumulated in the k-d order (cost within 3e-7 of the same
  * kernels on the caller's order); gradients are written through the permutation, so callers keep their own point order.
- * levels in 0..9; 0 = the caller's order, every unit evaluated (rounds 1-5).  Default 4 (environment HP_EMD_CULL at load time).
+ * levels in 0..9; 0 = the caller's order, every unit evaluated (rounds 1-5).  Default 3 (environment HP_EMD_CULL at load time).
  * Sets of more than 4096 points always run in the caller's order.  hp_approxmatch / hp_approxmatch_ws (whose `match` and `temp`
  * are returned in the caller's order) are never re-ordered.  Returns the previous setting. */
 /* [test hook: process-wide, not thread-safe — see the header comment] */
